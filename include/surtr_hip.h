@@ -1,0 +1,165 @@
+/* surtr_hip.h -- C ABI of the MI355X-native fracture engine (libsurtr_hip.so).
+ *
+ * The reference (W298/Surtr) has no FFI layer; its operator boundary for the
+ * fracture-event path is the trio of std::function tasks
+ *     m_fractureTask      Inc/Surtr.h:272, body Src/Surtr.cpp:1457-1504
+ *     m_refittingTask     Inc/Surtr.h:271, body Src/Surtr.cpp:1449-1455
+ *     m_initCompoundTask  Inc/Surtr.h:270, body Src/Surtr.cpp:1436-1447
+ * fanned out by Surtr::ApplyFracture (Src/Surtr.cpp:2098-2149), Refitting
+ * (2405-2413) and InitCompound (2499-2529).  The entry points below are what a
+ * host shim that keeps those C++ signatures binds.
+ *
+ * Conventions
+ *   - plain C types only; every array is a flat buffer with an explicit count;
+ *   - a solid (Poly::Polyhedron, Inc/Poly.h:15-32) is CSR: pos f32[3*V],
+ *     nbr_off u32[V+1], nbr i32[H] (neighbour rings, CCW seen from outside);
+ *   - a set of solids shares one vertex numbering: vert_off u32[n+1] gives the
+ *     vertex range of solid i, nbr_off is global over all vertices and the
+ *     entries of nbr are indices local to their solid;
+ *   - planes are float[4] = (nx,ny,nz,d); the kept side is n.x + d <= 0
+ *     (Poly::ClipPolyhedron, Src/Poly.cpp:265-500);
+ *   - errors are integer codes (the reference throws std::exception,
+ *     Src/Poly.cpp:258, Src/VMACH.cpp:91); 0 is success;
+ *   - one context per GPU; calls on a context are serialised by the caller;
+ *     contexts are independent (thread-compatible, not thread-safe);
+ *   - "dev" pointers are device (HBM) addresses, everything else is host memory.
+ */
+#ifndef SURTR_HIP_H
+#define SURTR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct surtr_ctx surtr_ctx;
+
+enum {
+    SURTR_OK = 0,
+    SURTR_E_INVALID = 1,   /* bad argument */
+    SURTR_E_TOPOLOGY = 2,  /* asymmetric neighbour links / vertex of degree < 3 (Src/Poly.cpp:253-260) */
+    SURTR_E_CAPACITY = 3,  /* a device arena or the caller's output buffer is too small */
+    SURTR_E_HIP = 4,       /* HIP runtime error, see surtr_last_error */
+    SURTR_E_STATE = 5,     /* call order violated (e.g. event before upload) */
+    SURTR_E_NOGPU = 6      /* no HIP device: the engine has no CPU fallback */
+};
+
+/* Event flags. */
+enum {
+    SURTR_EVT_REFIT = 1,   /* run m_refittingTask on every fragment's Convex */
+    SURTR_EVT_RENDER = 2   /* ExtractFaces + RenderPolyhedron(isConvex=false) of every Mesh */
+};
+
+/* Sizes of one event's result (all counts, not bytes). */
+typedef struct surtr_counts {
+    uint32_t n_frag;       /* non-empty (cell, piece, island) outputs */
+    uint32_t mesh_verts, mesh_nbrs;
+    uint32_t conv_verts, conv_nbrs;
+    uint32_t n_idx;        /* triangle indices (render buffers) */
+    uint32_t n_pairs;      /* (cell, piece) pairs processed */
+    uint32_t status;       /* device-side status word, SURTR_OK or an error code */
+} surtr_counts;
+
+/* Host-side view used by surtr_event_download: every pointer may be NULL to
+ * skip that array; otherwise it must hold the size noted (from surtr_counts). */
+typedef struct surtr_fragments {
+    int32_t* frag_ids;          /* 3*n_frag: cell, piece, island (cell-major order, Src/Surtr.cpp:2133-2146) */
+    uint32_t* mesh_vert_off;    /* n_frag+1 */
+    float* mesh_pos;            /* 3*mesh_verts */
+    uint32_t* mesh_nbr_off;     /* mesh_verts+1 (global over all fragments) */
+    int32_t* mesh_nbr;          /* mesh_nbrs, fragment-local indices */
+    uint32_t* conv_vert_off;    /* n_frag+1 */
+    float* conv_pos;            /* 3*conv_verts */
+    uint32_t* conv_nbr_off;     /* conv_verts+1 */
+    int32_t* conv_nbr;          /* conv_nbrs */
+    float* vnc;                 /* 9*mesh_verts: VertexNormalColor (Inc/Mesh.h:4-13) of every Mesh vertex */
+    uint32_t* idx_off;          /* n_frag+1 */
+    uint32_t* idx;              /* n_idx, fragment-local vertex indices (Src/Poly.cpp:708-713) */
+} surtr_fragments;
+
+/* ---- life cycle -------------------------------------------------------- */
+int surtr_create(int device, surtr_ctx** out);
+void surtr_destroy(surtr_ctx* ctx);
+const char* surtr_strerror(int code);
+const char* surtr_last_error(surtr_ctx* ctx);
+/* Use this HIP stream (hipStream_t passed as void*) for all work; NULL = default stream. */
+int surtr_set_stream(surtr_ctx* ctx, void* hip_stream);
+/* Override the per-workgroup scratch capacities (vertices, neighbour entries); 0 = automatic. */
+int surtr_set_scratch(surtr_ctx* ctx, uint32_t max_verts, uint32_t max_nbrs);
+/* Override the result arena capacities (vertices, neighbour entries, indices); 0 = automatic. */
+int surtr_set_arena(surtr_ctx* ctx, uint64_t verts, uint64_t nbrs, uint64_t idx);
+
+/* ---- inputs ------------------------------------------------------------ */
+/* Replaces compound.PieceVec (Inc/Surtr.h:113-134): n pieces, each a (Convex, Mesh)
+ * pair of solids.  Copies host -> device once; validates neighbour symmetry
+ * and degree >= 3 (SURTR_E_TOPOLOGY). */
+int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n_pieces,
+                        const uint32_t* mesh_vert_off, const float* mesh_pos,
+                        const uint32_t* mesh_nbr_off, const int32_t* mesh_nbr,
+                        const uint32_t* conv_vert_off, const float* conv_pos,
+                        const uint32_t* conv_nbr_off, const int32_t* conv_nbr);
+
+/* Replaces the std::vector<VMACH::Polygon3D> fracture pattern
+ * (Src/Surtr.cpp:1806-1807): n_cells cells, cell c owns faces
+ * [face_off[c], face_off[c+1]); v012 holds the first three vertices of every
+ * face in pattern space (9 floats), which is all ConstructFacePlane reads
+ * (Src/VMACH.cpp:302-310). */
+int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_off, const float* v012);
+
+/* Polygon3D::Scale + Translate + ConstructFacePlane for every face, on the
+ * device (Src/VMACH.cpp:506-534; per event at Src/Surtr.cpp:1891-1896). */
+int surtr_place_cells(surtr_ctx* ctx, const float scale[3], const float translate[3]);
+
+/* Alternative to pattern+place: give the cell planes directly. */
+int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_off, const float* planes);
+
+/* ---- the event --------------------------------------------------------- */
+/* ApplyFracture over cells [cell_begin, cell_end) x all pieces on device-resident
+ * inputs: clip Convex, clip Mesh, split islands, then (flags) refit and
+ * triangulate.  `outside` (n_pieces bytes, may be NULL) marks pieces skipped as
+ * in Src/Surtr.cpp:1463-1464.  Results stay on the device; counts are returned.
+ * Synchronises the stream once to read the counts. */
+int surtr_fracture_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end,
+                         const uint8_t* outside, uint32_t flags, surtr_counts* counts);
+
+/* Same, but does not synchronise or read anything back: for timing loops.
+ * The counts of the last event are fetched with surtr_event_counts. */
+int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end,
+                               const uint8_t* outside, uint32_t flags);
+int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts);
+
+/* Bytes of the packed device blob holding the last event's fragments. */
+size_t surtr_event_blob_bytes(const surtr_counts* counts);
+/* Packs the last event's fragments into one contiguous device buffer (for an
+ * all-gather over RCCL or a single D2H copy).  Layout: see DESIGN.md. */
+int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity_bytes);
+/* Splits a host copy of a blob into the arrays of surtr_fragments. */
+int surtr_blob_unpack_host(const void* host_blob, size_t bytes, surtr_counts* counts, surtr_fragments* out);
+/* Convenience: pack + copy to host + unpack into caller arrays. */
+int surtr_event_download(surtr_ctx* ctx, surtr_fragments* out);
+
+/* ---- single-solid operators (the Poly / Kdop API surface) -------------- */
+/* Poly::ClipPolyhedron(polyhedron, planes) for one solid, Src/Poly.cpp:556-566.
+ * Count-then-fill: call with out_* NULL to get sizes. */
+int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr,
+                          uint32_t n_planes, const float* planes,
+                          uint32_t* out_nv, uint32_t* out_nh, float* out_pos, uint32_t* out_nbr_off, int32_t* out_nbr);
+
+/* ---- host-side helpers of the harness (no GPU needed) ------------------ */
+/* Poly::ExtractNeighborFromMesh, Src/Poly.cpp:128-263: welded triangle soup ->
+ * neighbour rings.  nbr must hold 2*3*n_tris entries at most; returns
+ * SURTR_E_TOPOLOGY where the reference throws. */
+int surtr_neighbors_from_mesh(uint32_t nv, uint32_t n_tris, const int32_t* tris, uint32_t* nbr_off, int32_t* nbr);
+
+/* Canonical bounded Voronoi cells of n seeds in the unit box (replaces the
+ * voro++ call of Src/Surtr.cpp:2003-2070; see DESIGN.md for the face order).
+ * Count-then-fill: pass NULL arrays to get n_faces / n_face_verts. */
+int surtr_voronoi_cells(uint32_t n, const double* seeds, uint32_t* n_faces, uint32_t* n_face_verts,
+                        uint32_t* cell_face_off, int32_t* face_gen, uint32_t* face_vert_off, double* verts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURTR_HIP_H */

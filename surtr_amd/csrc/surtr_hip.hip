@@ -1,0 +1,1438 @@
+// surtr_hip.hip -- kernels of the fracture event + the C ABI of include/surtr_hip.h.
+//
+// Event pipeline (all on the caller's HIP stream, inputs resident in HBM):
+//   k_place_cells   A3   Polygon3D::Scale/Translate + ConstructFacePlane      (Src/VMACH.cpp:302-310, 506-534)
+//   k_clip_pairs    A7+A8+A11  one workgroup per (cell, piece): clip Convex, clip Mesh, label islands,
+//                        park the result in the arena                          (Src/Surtr.cpp:1457-1504, Src/Poly.cpp:265-500)
+//   k_frag_table    A11  cell-major fragment table                             (Src/Surtr.cpp:2133-2146)
+//   k_refit         A12  limit-4 hull normals + k-DOP slabs + clip Convex      (Src/Surtr.cpp:1449-1455)
+//   k_faces         A9+A10  ExtractFaces + EarClipping of every Mesh           (Src/Poly.cpp:89-126, 764-913)
+//   k_out_scan / k_pack  coalesced write of the packed fragment blob
+// There is no CPU fallback: without a HIP device surtr_create fails with SURTR_E_NOGPU.
+#ifndef SURTR_EMUL
+#include <hip/hip_runtime.h>
+#endif
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/surtr_hip.h"
+#include "clip_core.h"
+
+using namespace surtr;
+
+// ------------------------------------------------------------------ records
+struct PairRec
+{
+    uint32_t cv_off, cv_n, ch_off, ch_n;   // clipped Convex in the arena
+    uint32_t mv_off, mv_n, mh_off, mh_n;   // clipped Mesh (all islands, island-major)
+    uint32_t ni, isl_off;                  // islands and where their (nv, nh) records start
+    uint32_t status, pad;
+};
+
+struct FragRec
+{
+    int32_t cell, piece, island;
+    uint32_t mv_off, mv_n, mh_off, mh_n;
+    uint32_t cv_off, cv_n, ch_off, ch_n;
+    uint32_t idx_off, idx_n;
+    // output bases (filled by k_out_scan)
+    uint32_t o_mv, o_mh, o_cv, o_ch, o_idx;
+};
+
+struct Arena
+{
+    float* pos; uint32_t* loff; uint32_t* llen; int32_t* nbr; uint32_t* idx;
+    uint2* isl;
+    uint32_t capV, capH, capI, capIsl;
+    uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=work queue [5]=status [6]=work queue 2 [7]=work queue 3
+};
+
+struct Pieces
+{
+    const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri;
+    const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri;
+    uint32_t n;
+};
+
+struct ScratchPool
+{
+    char* base; size_t per_wg;
+    uint32_t CV, CH, VMAX, NB;
+};
+
+__device__ static Scratch carve(const ScratchPool& P, uint32_t wg)
+{
+    Scratch S;
+    char* p = P.base + (size_t)wg * P.per_wg;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    for (int i = 0; i < 2; ++i)
+    {
+        S.b[i].pos = (float*)take((size_t)P.CV * 12);
+        S.b[i].loff = (uint32_t*)take((size_t)P.CV * 4);
+        S.b[i].llen = (uint32_t*)take((size_t)P.CV * 4);
+        S.b[i].comp = (int8_t*)take((size_t)P.CV);
+        S.b[i].nbr = (int32_t*)take((size_t)P.CH * 4);
+    }
+    S.aux0 = (uint32_t*)take((size_t)P.CV * 4);
+    S.aux1 = (uint32_t*)take((size_t)P.CV * 4);
+    S.aux2 = (uint32_t*)take((size_t)P.CV * 4);
+    S.fc = (uint8_t*)take((size_t)P.VMAX);
+    S.newid = (int32_t*)take((size_t)P.VMAX * 4);
+    S.blk = (uint2*)take((size_t)P.NB * 8);
+    S.CV = P.CV; S.CH = P.CH;
+    return S;
+}
+
+static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX, uint32_t NB)
+{
+    auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t t = 0;
+    for (int i = 0; i < 2; ++i) t += r((size_t)CV * 12) + 2 * r((size_t)CV * 4) + r((size_t)CV) + r((size_t)CH * 4);
+    t += 3 * r((size_t)CV * 4) + r((size_t)VMAX) + r((size_t)VMAX * 4) + r((size_t)NB * 8);
+    return t;
+}
+
+// ------------------------------------------------------------- small helpers
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float t = ax * bx + ay * by;
+    return t + az * bz;
+}
+
+// Plane(p0,p1,p2): XMPlaneFromPoints, normalised (SimpleMath.inl:2773-2780).
+__device__ __forceinline__ float4 plane_from_points(const float* p0, const float* p1, const float* p2)
+{
+    const float ax = p0[0] - p1[0], ay = p0[1] - p1[1], az = p0[2] - p1[2];
+    const float bx = p0[0] - p2[0], by = p0[1] - p2[1], bz = p0[2] - p2[2];
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float len = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+    if (len != 0.f) { nx = nx / len; ny = ny / len; nz = nz / len; }
+    else { nx = 0.f; ny = 0.f; nz = 0.f; }
+    return make_float4(nx, ny, nz, -dot3(nx, ny, nz, p0[0], p0[1], p0[2]));
+}
+
+// ------------------------------------------------------------ k_place_cells
+__global__ void k_place_cells(uint32_t nfaces, const float* __restrict__ v012, float sx, float sy, float sz,
+                              float tx, float ty, float tz, float4* __restrict__ planes)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nfaces) return;
+    float p[9];
+    for (int i = 0; i < 3; ++i)
+    {
+        p[3 * i] = v012[9 * f + 3 * i] * sx + tx;
+        p[3 * i + 1] = v012[9 * f + 3 * i + 1] * sy + ty;
+        p[3 * i + 2] = v012[9 * f + 3 * i + 2] * sz + tz;
+    }
+    planes[f] = plane_from_points(p, p + 3, p + 6);
+}
+
+// ------------------------------------------------------------- arena output
+// Copies a packed solid (rings in vertex order) from a scratch buffer to the arena.
+__device__ static void park_solid(const Buf& B, uint32_t n, uint32_t nh, const Arena& A, uint32_t voff, uint32_t hoff)
+{
+    for (uint32_t v = threadIdx.x; v < n; v += SURTR_WG)
+    {
+        A.pos[3 * (size_t)(voff + v)] = B.pos[3 * v];
+        A.pos[3 * (size_t)(voff + v) + 1] = B.pos[3 * v + 1];
+        A.pos[3 * (size_t)(voff + v) + 2] = B.pos[3 * v + 2];
+        A.loff[voff + v] = hoff + B.loff[v];
+        A.llen[voff + v] = B.llen[v];
+    }
+    for (uint32_t e = threadIdx.x; e < nh; e += SURTR_WG) A.nbr[hoff + e] = B.nbr[e];
+}
+
+__device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
+                                  uint32_t& voff, uint32_t& hoff, uint32_t& ioff)
+{
+    if (threadIdx.x == 0)
+    {
+        sh.misc[0] = atomicAdd(&A.cursors[0], nv);
+        sh.misc[1] = atomicAdd(&A.cursors[1], nh);
+        sh.misc[2] = nisl ? atomicAdd(&A.cursors[3], nisl) : 0u;
+    }
+    __syncthreads();
+    voff = sh.misc[0]; hoff = sh.misc[1]; ioff = sh.misc[2];
+    const bool ok = (uint64_t)voff + nv <= A.capV && (uint64_t)hoff + nh <= A.capH && (uint64_t)ioff + nisl <= A.capIsl;
+    __syncthreads();
+    return ok;
+}
+
+// -------------------------------------------------------------- k_clip_pairs
+__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs, const uint8_t* __restrict__ outside,
+                                                         ScratchPool pool, Arena A, PairRec* __restrict__ pairs)
+{
+    __shared__ Shared sh;
+    Scratch S = carve(pool, blockIdx.x);
+    const uint32_t tid = threadIdx.x;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[4], 1u);
+        __syncthreads();
+        const uint32_t p = sh.misc[7];
+        if (p >= n_pairs) break;
+        const uint32_t cell = cell_begin + p / P.n, piece = p % P.n;
+        PairRec rec;
+        memset(&rec, 0, sizeof(rec));
+        bool skip = outside != nullptr && outside[piece] != 0;
+        const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
+        if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
+        uint32_t cn = 0, cb = 0, chn = 0, mn = 0, mb = 0, mhn = 0;
+        int err = 0;
+        if (!skip)
+        {
+            for (uint32_t k = tid; k < F; k += SURTR_WG) sh.planes[k] = planes[f0 + k];
+            __syncthreads();
+            // Convex first (Src/Surtr.cpp:1466-1468)
+            const uint32_t c0 = P.cvo[piece];
+            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0};
+            err = clip_solid(cin, F, S, sh, &cn, &cb, &chn);
+            __syncthreads();
+        }
+        if (!skip && err == 0 && cn > 0)
+        {
+            uint32_t voff, hoff, ioff;
+            if (!arena_take(A, sh, cn, chn, 0, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
+            else
+            {
+                park_solid(S.b[cb], cn, chn, A, voff, hoff);
+                rec.cv_off = voff; rec.cv_n = cn; rec.ch_off = hoff; rec.ch_n = chn;
+            }
+            __syncthreads();
+            if (err == 0)
+            {
+                const uint32_t m0 = P.mvo[piece];
+                SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0};
+                err = clip_solid(min, F, S, sh, &mn, &mb, &mhn);
+                __syncthreads();
+            }
+        }
+        if (!skip && err == 0 && cn > 0 && mn > 0)
+        {
+            // ---- islands: min-label propagation (CheckMeshIsland, Src/Surtr.cpp:2157-2201) ----
+            Buf& B = S.b[mb];
+            uint32_t* lab = S.aux0;
+            for (uint32_t v = tid; v < mn; v += SURTR_WG) lab[v] = v;
+            __syncthreads();
+            while (true)
+            {
+                if (tid == 0) sh.changed = 0;
+                __syncthreads();
+                bool ch = false;
+                for (uint32_t v = tid; v < mn; v += SURTR_WG)
+                {
+                    uint32_t m = lab[v];
+                    const int32_t* r = B.nbr + B.loff[v];
+                    const uint32_t len = B.llen[v];
+                    for (uint32_t q = 0; q < len; ++q) { const uint32_t o = lab[r[q]]; m = o < m ? o : m; }
+                    const uint32_t mm = lab[m];
+                    m = mm < m ? mm : m;
+                    if (m < lab[v]) { lab[v] = m; ch = true; }
+                }
+                if (ch) sh.changed = 1;
+                __syncthreads();
+                if (!sh.changed) break;
+            }
+            auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2(lab[v] == v ? 1u : 0u, 0u); };
+            uint32_t ni = 0, dum = 0;
+            scan_blocks(mn, S.blk, sh, rootfn, ni, dum);
+            uint32_t voff, hoff, ioff;
+            if (!arena_take(A, sh, mn, mhn, ni, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
+            else if (ni == 1)
+            {
+                park_solid(B, mn, mhn, A, voff, hoff);
+                if (tid == 0) A.isl[ioff] = make_uint2(mn, mhn);
+            }
+            else
+            {
+                // island index of every root = its rank among roots (discovery order = lowest vertex first)
+                uint32_t* irank = S.aux1; uint32_t* local = S.aux2;
+                const uint32_t nb = (mn + SURTR_LANES - 1u) >> SURTR_LSH;
+                for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+                {
+                    const uint32_t v = (b << SURTR_LSH) + lane_id();
+                    uint2 c = make_uint2(0u, 0u);
+                    if (v < mn) c = rootfn(v);
+                    const uint2 e = wave_excl2(c);
+                    if (v < mn && c.x) irank[v] = S.blk[b].x + e.x;
+                }
+                __syncthreads();
+                uint32_t vbase = 0, hbase = 0;
+                for (uint32_t t = 0; t < ni; ++t)
+                {
+                    auto isfn = [&](uint32_t v) -> uint2 {
+                        return (irank[lab[v]] == t) ? make_uint2(1u, B.llen[v]) : make_uint2(0u, 0u);
+                    };
+                    uint32_t tv = 0, th = 0;
+                    scan_blocks(mn, S.blk, sh, isfn, tv, th);
+                    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+                    {
+                        const uint32_t v = (b << SURTR_LSH) + lane_id();
+                        uint2 c = make_uint2(0u, 0u);
+                        if (v < mn) c = isfn(v);
+                        const uint2 e = wave_excl2(c);
+                        if (v < mn && c.x)
+                        {
+                            const uint32_t lv = S.blk[b].x + e.x;
+                            const uint32_t dv = voff + vbase + lv;
+                            local[v] = lv;
+                            A.pos[3 * (size_t)dv] = B.pos[3 * v]; A.pos[3 * (size_t)dv + 1] = B.pos[3 * v + 1];
+                            A.pos[3 * (size_t)dv + 2] = B.pos[3 * v + 2];
+                            A.llen[dv] = c.y;
+                            A.loff[dv] = hoff + hbase + S.blk[b].y + e.y;
+                        }
+                    }
+                    if (tid == 0) A.isl[ioff + t] = make_uint2(tv, th);
+                    __syncthreads();
+                    // rings of this island
+                    for (uint32_t v = tid; v < mn; v += SURTR_WG)
+                    {
+                        if (irank[lab[v]] != t) continue;
+                        const uint32_t dv = voff + vbase + local[v];
+                        const int32_t* r = B.nbr + B.loff[v];
+                        int32_t* d = A.nbr + A.loff[dv];
+                        const uint32_t len = B.llen[v];
+                        for (uint32_t q = 0; q < len; ++q) d[q] = (int32_t)local[r[q]];
+                    }
+                    vbase += tv; hbase += th;
+                    __syncthreads();
+                }
+            }
+            if (err == 0)
+            {
+                rec.mv_off = voff; rec.mv_n = mn; rec.mh_off = hoff; rec.mh_n = mhn; rec.ni = ni; rec.isl_off = ioff;
+            }
+        }
+        if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+        if (tid == 0) pairs[p] = rec;
+    }
+}
+
+// -------------------------------------------------------------- k_frag_table
+// One workgroup: exclusive scan of islands per pair -> fragment records in cell-major order.
+__global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restrict__ pairs, uint32_t n_pairs,
+                                                         uint32_t n_pieces, uint32_t cell_begin, Arena A,
+                                                         uint2* __restrict__ blk, FragRec* __restrict__ frags,
+                                                         uint32_t cap_frags, surtr_counts* __restrict__ counts)
+{
+    __shared__ Shared sh;
+    auto fn = [&](uint32_t p) -> uint2 { return make_uint2(pairs[p].ni, 0u); };
+    uint32_t nf = 0, dum = 0;
+    scan_blocks(n_pairs, blk, sh, fn, nf, dum);
+    const uint32_t nb = (n_pairs + SURTR_LANES - 1u) >> SURTR_LSH;
+    if (nf <= cap_frags)
+    {
+        for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+        {
+            const uint32_t p = (b << SURTR_LSH) + lane_id();
+            uint2 c = make_uint2(0u, 0u);
+            if (p < n_pairs) c = fn(p);
+            const uint2 e = wave_excl2(c);
+            if (p < n_pairs && c.x)
+            {
+                const PairRec r = pairs[p];
+                uint32_t f = blk[b].x + e.x;
+                uint32_t vo = r.mv_off, ho = r.mh_off;
+                for (uint32_t t = 0; t < r.ni; ++t, ++f)
+                {
+                    const uint2 is = A.isl[r.isl_off + t];
+                    FragRec fr;
+                    fr.cell = (int32_t)(cell_begin + p / n_pieces); fr.piece = (int32_t)(p % n_pieces); fr.island = (int32_t)t;
+                    fr.mv_off = vo; fr.mv_n = is.x; fr.mh_off = ho; fr.mh_n = is.y;
+                    fr.cv_off = r.cv_off; fr.cv_n = r.cv_n; fr.ch_off = r.ch_off; fr.ch_n = r.ch_n;
+                    fr.idx_off = 0; fr.idx_n = 0; fr.o_mv = fr.o_mh = fr.o_cv = fr.o_ch = fr.o_idx = 0;
+                    frags[f] = fr;
+                    vo += is.x; ho += is.y;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0)
+    {
+        counts->n_frag = nf <= cap_frags ? nf : 0u;
+        counts->n_pairs = n_pairs;
+        if (nf > cap_frags) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY);
+    }
+}
+
+// ------------------------------------------------------------------ k_refit
+// argmax with "first maximum wins" (std::max_element) over the workgroup.
+struct ArgF { float v; uint32_t i; };
+struct ArgD { double v; uint32_t i; };
+
+template <class T, class A>
+__device__ static A wg_argmax(A mine, A* slots /* shared, SURTR_NWAVE */)
+{
+    // wave reduce
+    for (int d = SURTR_LANES / 2; d >= 1; d >>= 1)
+    {
+        A o;
+        o.v = __shfl_down(mine.v, d, SURTR_LANES);
+        o.i = __shfl_down(mine.i, d, SURTR_LANES);
+        if (o.i != 0xFFFFFFFFu && (mine.i == 0xFFFFFFFFu || o.v > mine.v || (o.v == mine.v && o.i < mine.i))) mine = o;
+    }
+    __syncthreads();
+    if (lane_id() == 0) slots[wave_id()] = mine;
+    __syncthreads();
+    A best = slots[0];
+    for (uint32_t q = 1; q < SURTR_NWAVE; ++q)
+    {
+        const A o = slots[q];
+        if (o.i != 0xFFFFFFFFu && (best.i == 0xFFFFFFFFu || o.v > best.v || (o.v == best.v && o.i < best.i))) best = o;
+    }
+    __syncthreads();
+    return best;
+}
+
+__device__ __forceinline__ float hull_vol(const float* a, const float* b, const float* c, const float* p)
+{
+    // VMACH::ConvexHull::Volume, Src/VMACH.cpp:922-939
+    const float ax = a[0] - p[0], ay = a[1] - p[1], az = a[2] - p[2];
+    const float bx = b[0] - p[0], by = b[1] - p[1], bz = b[2] - p[2];
+    const float cx = c[0] - p[0], cy = c[1] - p[1], cz = c[2] - p[2];
+    return ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx);
+}
+
+__global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
+                                                    ScratchPool pool, Arena A)
+{
+    __shared__ Shared sh;
+    __shared__ ArgF slotF[SURTR_NWAVE];
+    __shared__ ArgD slotD[SURTR_NWAVE];
+    __shared__ float hp[4][3];
+    __shared__ float nrm[4][3];
+    __shared__ ArgF kmin[4][SURTR_NWAVE], kmax[4][SURTR_NWAVE];
+    Scratch S = carve(pool, blockIdx.x);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nf = counts->n_frag;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[6], 1u);
+        __syncthreads();
+        const uint32_t f = sh.misc[7];
+        if (f >= nf) break;
+        FragRec fr = frags[f];
+        const float* mp = A.pos + 3 * (size_t)fr.mv_off;
+        const uint32_t n = fr.mv_n;
+        // ---- BuildFirstHull (Src/VMACH.cpp:1036-1085) with limit min(n,4) = 4 ----
+        ArgF a; a.i = 0xFFFFFFFFu; a.v = 0.f;
+        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        {
+            const float x = mp[3 * v];
+            if (a.i == 0xFFFFFFFFu || x > a.v) { a.v = x; a.i = v; }
+        }
+        a = wg_argmax<float, ArgF>(a, slotF);
+        const uint32_t i1 = a.i;
+        const float p1x = mp[3 * i1], p1y = mp[3 * i1 + 1], p1z = mp[3 * i1 + 2];
+        ArgD d; d.i = 0xFFFFFFFFu; d.v = 0.0;
+        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        {
+            const double dx = (double)(mp[3 * v] - p1x), dy = (double)(mp[3 * v + 1] - p1y), dz = (double)(mp[3 * v + 2] - p1z);
+            const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+            if (d.i == 0xFFFFFFFFu || dist > d.v) { d.v = dist; d.i = v; }
+        }
+        d = wg_argmax<double, ArgD>(d, slotD);
+        const uint32_t i2 = d.i;
+        const float p2x = mp[3 * i2], p2y = mp[3 * i2 + 1], p2z = mp[3 * i2 + 2];
+        a.i = 0xFFFFFFFFu; a.v = 0.f;
+        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        {
+            // ConvexHullFace(v1, v2, p).CalcArea(): 0.5 * |(v2-v1) x (p-v1)|
+            const float ux = p2x - p1x, uy = p2y - p1y, uz = p2z - p1z;
+            const float wx = mp[3 * v] - p1x, wy = mp[3 * v + 1] - p1y, wz = mp[3 * v + 2] - p1z;
+            const float cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+            const float area = 0.5f * sqrtf(dot3(cx, cy, cz, cx, cy, cz));
+            if (a.i == 0xFFFFFFFFu || area > a.v) { a.v = area; a.i = v; }
+        }
+        a = wg_argmax<float, ArgF>(a, slotF);
+        const uint32_t i3 = a.i;
+        const float q1[3] = {p1x, p1y, p1z}, q2[3] = {p2x, p2y, p2z};
+        const float q3[3] = {mp[3 * i3], mp[3 * i3 + 1], mp[3 * i3 + 2]};
+        a.i = 0xFFFFFFFFu; a.v = 0.f;
+        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        {
+            const float vol = hull_vol(q1, q2, q3, mp + 3 * v);
+            if (a.i == 0xFFFFFFFFu || vol > a.v) { a.v = vol; a.i = v; }
+        }
+        a = wg_argmax<float, ArgF>(a, slotF);
+        const uint32_t i4 = a.i;
+        if (tid == 0)
+        {
+            const float q4[3] = {mp[3 * i4], mp[3 * i4 + 1], mp[3 * i4 + 2]};
+            // faces in creation order, each rewound when Volume(face, inner) < 0 (:955-969)
+            const float* fv[4][3] = {{q1, q2, q3}, {q1, q2, q4}, {q1, q3, q4}, {q2, q3, q4}};
+            const float* inner[4] = {q4, q3, q2, q1};
+            for (int k = 0; k < 4; ++k)
+            {
+                const float* v0 = fv[k][0]; const float* v1 = fv[k][1]; const float* v2 = fv[k][2];
+                if (hull_vol(v0, v1, v2, inner[k]) < 0.f) { const float* t = v0; v0 = v2; v2 = t; }
+                // GenerateICHNormal (Src/Surtr.cpp:1961-1974): normalize((v1-v0) x (v2-v0))
+                const float ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2];
+                const float bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
+                float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+                const float len = sqrtf(dot3(nx, ny, nz, nx, ny, nz));
+                if (len != 0.f) { nx = nx / len; ny = ny / len; nz = nz / len; } else { nx = ny = nz = 0.f; }
+                nrm[k][0] = nx; nrm[k][1] = ny; nrm[k][2] = nz;
+            }
+        }
+        __syncthreads();
+        // ---- Kdop::Calc(Polyhedron) (Src/Kdop.cpp:92-115): first minimum / first maximum of n.v ----
+        for (int k = 0; k < 4; ++k)
+        {
+            ArgF lo, hi; lo.i = hi.i = 0xFFFFFFFFu; lo.v = hi.v = 0.f;
+            const float nx = nrm[k][0], ny = nrm[k][1], nz = nrm[k][2];
+            for (uint32_t v = tid; v < n; v += SURTR_WG)
+            {
+                const float t = dot3(mp[3 * v], mp[3 * v + 1], mp[3 * v + 2], nx, ny, nz);
+                if (hi.i == 0xFFFFFFFFu || t > hi.v) { hi.v = t; hi.i = v; }
+                if (lo.i == 0xFFFFFFFFu || -t > lo.v) { lo.v = -t; lo.i = v; }
+            }
+            hi = wg_argmax<float, ArgF>(hi, slotF);
+            lo = wg_argmax<float, ArgF>(lo, slotF);
+            if (tid == 0)
+            {
+                // MinPlane = Plane(vert, -n), MaxPlane = Plane(vert, n); order Min, Max (:166-179)
+                const float* a0 = mp + 3 * lo.i; const float* a1 = mp + 3 * hi.i;
+                sh.planes[2 * k] = make_float4(-nx, -ny, -nz, -dot3(a0[0], a0[1], a0[2], -nx, -ny, -nz));
+                sh.planes[2 * k + 1] = make_float4(nx, ny, nz, -dot3(a1[0], a1[1], a1[2], nx, ny, nz));
+            }
+        }
+        __syncthreads();
+        if (tid == 0) for (int k = 0; k < 8; ++k) SURTR_DBG("refit f=%u plane %d: %.9g %.9g %.9g %.9g\n", f, k, sh.planes[k].x, sh.planes[k].y, sh.planes[k].z, sh.planes[k].w);
+        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr};
+        // arena rings are absolute; make them relative by handing the absolute base (loff indexes A.nbr directly)
+        uint32_t cn = 0, cb = 0, chn = 0;
+        int err = clip_solid(cin, 8, S, sh, &cn, &cb, &chn);
+        __syncthreads();
+        if (err == 0)
+        {
+            uint32_t voff = 0, hoff = 0, ioff = 0;
+            if (cn > 0 && !arena_take(A, sh, cn, chn, 0, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
+            else
+            {
+                if (cn > 0) park_solid(S.b[cb], cn, chn, A, voff, hoff);
+                if (tid == 0)
+                {
+                    fr.cv_off = voff; fr.cv_n = cn; fr.ch_off = hoff; fr.ch_n = chn;
+                    frags[f] = fr;
+                }
+            }
+        }
+        if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
+        (void)kmin; (void)kmax; (void)hp;
+    }
+}
+
+// ------------------------------------------------------------------ k_faces
+struct FaceScratch
+{
+    int32_t* base; size_t per_wg; uint32_t HF;   // HF = max half-edges of one fragment
+};
+
+__device__ __forceinline__ bool on_right(const float* a, const float* b, const float* c, float nx, float ny, float nz)
+{
+    // VMACH::OnYourRight, Src/VMACH.cpp:1240-1243
+    const float ux = b[0] - a[0], uy = b[1] - a[1], uz = b[2] - a[2];
+    const float wx = c[0] - a[0], wy = c[1] - a[1], wz = c[2] - a[2];
+    const float cx = uy * wz - uz * wy, cy = uz * wx - ux * wz, cz = ux * wy - uy * wx;
+    return dot3(cx, cy, cz, nx, ny, nz) > 0.f;
+}
+
+// Poly::EarClipping (Src/Poly.cpp:764-913) for one face, one lane.  loop = vertex ids of the face;
+// tmp = 3*N ints (prev, next, reflex).  Writes vertex ids (3 per triangle) to out; returns the count.
+__device__ static uint32_t ear_clip_face(const float* pos, const int32_t* loop, int N, int32_t* tmp, uint32_t* out)
+{
+    if (N <= 2) return 0;
+    if (N == 3) { out[0] = loop[0]; out[1] = loop[1]; out[2] = loop[2]; return 3; }
+    const float* A0 = pos + 3 * loop[0]; const float* B0 = pos + 3 * loop[1]; const float* C0 = pos + 3 * loop[2];
+    float nx, ny, nz;
+    {
+        const float ux = B0[0] - A0[0], uy = B0[1] - A0[1], uz = B0[2] - A0[2];
+        const float wx = C0[0] - A0[0], wy = C0[1] - A0[1], wz = C0[2] - A0[2];
+        nx = uy * wz - uz * wy; ny = uz * wx - ux * wz; nz = ux * wy - uy * wx;
+    }
+    {   // IsCCW (:753-762)
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int v = 0; v < N; ++v)
+        {
+            const float* p = pos + 3 * loop[v]; const float* q = pos + 3 * loop[(v + 1) % N];
+            const float ux = p[0] - A0[0], uy = p[1] - A0[1], uz = p[2] - A0[2];
+            const float wx = q[0] - A0[0], wy = q[1] - A0[1], wz = q[2] - A0[2];
+            sx = sx + (uy * wz - uz * wy); sy = sy + (uz * wx - ux * wz); sz = sz + (ux * wy - uy * wx);
+        }
+        if (dot3(sx, sy, sz, nx, ny, nz) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    }
+    int32_t* prv = tmp; int32_t* nxt = tmp + N; int32_t* rfx = tmp + 2 * N;
+    for (int i = 0; i < N; ++i) { prv[i] = (i + N - 1) % N; nxt[i] = (i + 1) % N; }
+    for (int i = 0; i < N; ++i)
+        rfx[i] = on_right(pos + 3 * loop[prv[i]], pos + 3 * loop[i], pos + 3 * loop[nxt[i]], nx, ny, nz) ? 0 : 1;
+    int skipped = 0, left = N, cur = 0;
+    uint32_t at = 0;
+    while (left > 3)
+    {
+        const int p = prv[cur], n = nxt[cur];
+        bool ear = rfx[cur] == 0;
+        if (ear)
+        {
+            const float* a = pos + 3 * loop[p]; const float* b = pos + 3 * loop[cur]; const float* c = pos + 3 * loop[n];
+            for (int r = 0; r < N && ear; ++r)
+            {
+                if (!rfx[r]) continue;                    // reflexVertices, in index order
+                if (r == p || r == n) continue;
+                const float* q = pos + 3 * loop[r];
+                if ((q[0] == a[0] && q[1] == a[1] && q[2] == a[2]) || (q[0] == b[0] && q[1] == b[1] && q[2] == b[2])) continue;
+                if (!on_right(a, b, q, nx, ny, nz)) continue;
+                if (!on_right(b, c, q, nx, ny, nz)) continue;
+                if (!on_right(c, a, q, nx, ny, nz)) continue;
+                ear = false;
+            }
+        }
+        if (ear)
+        {
+            out[at] = loop[p]; out[at + 1] = loop[cur]; out[at + 2] = loop[n];
+            nxt[p] = n; prv[n] = p;
+            const int adj[2] = {p, n};
+            for (int k = 0; k < 2; ++k)
+            {
+                const int v = adj[k];
+                if (!rfx[v]) continue;
+                rfx[v] = on_right(pos + 3 * loop[prv[v]], pos + 3 * loop[v], pos + 3 * loop[nxt[v]], nx, ny, nz) ? 0 : 1;
+            }
+            at += 3; --left; skipped = 0;
+        }
+        else if (++skipped > left) return 0;             // stalled: the face is dropped (:899-903)
+        cur = n;
+    }
+    out[at] = loop[prv[cur]]; out[at + 1] = loop[cur]; out[at + 2] = loop[nxt[cur]];
+    return at + 3;
+}
+
+__global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
+                                                    FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
+                                                    Arena A)
+{
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nf = counts->n_frag;
+    int32_t* base = FS.base + (size_t)blockIdx.x * FS.per_wg;
+    const uint32_t HF = FS.HF;
+    int32_t* keyA = base; int32_t* keyB = base + HF; int32_t* nxA = base + 2 * (size_t)HF; int32_t* nxB = base + 3 * (size_t)HF;
+    int32_t* loopbuf = base + 4 * (size_t)HF; int32_t* eartmp = base + 5 * (size_t)HF;   // 3*HF
+    uint32_t* tri = (uint32_t*)(base + 8 * (size_t)HF);                                   // 3*HF
+    uint32_t* fcnt = (uint32_t*)(base + 11 * (size_t)HF);                                 // HF (per owner edge)
+    uint2* blk = blkpool + (size_t)blockIdx.x * blk_per_wg;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[7], 1u);
+        __syncthreads();
+        const uint32_t f = sh.misc[7];
+        if (f >= nf) break;
+        FragRec fr = frags[f];
+        const uint32_t n = fr.mv_n, H = fr.mh_n;
+        if (H > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY); continue; }
+        const float* pos = A.pos + 3 * (size_t)fr.mv_off;
+        const uint32_t* loff = A.loff + fr.mv_off; const uint32_t* llen = A.llen + fr.mv_off;
+        const int32_t* nbr = A.nbr + fr.mh_off;           // ring of v starts at loff[v]-mh_off
+        // 1. successor half-edge in the face loop; half-edge id = position in the packed ring array
+        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        {
+            const uint32_t lo = loff[v] - fr.mh_off, len = llen[v];
+            for (uint32_t s = 0; s < len; ++s)
+            {
+                const int32_t b = nbr[lo + s];
+                const uint32_t lb = loff[b] - fr.mh_off, nbq = llen[b];
+                uint32_t q = 0;
+                while (q < nbq && nbr[lb + q] != (int32_t)v) ++q;
+                const uint32_t sq = (q == 0) ? nbq - 1 : q - 1;   // FaceLoop
+                nxA[lo + s] = (int32_t)(lb + sq);
+                keyA[lo + s] = (int32_t)(lo + s);
+            }
+        }
+        __syncthreads();
+        // 2. minimum half-edge id of every loop by pointer jumping
+        int32_t* kc = keyA; int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
+        for (uint32_t span = 1; span < H; span <<= 1)
+        {
+            for (uint32_t e = tid; e < H; e += SURTR_WG)
+            {
+                const int32_t t = xc[e];
+                const int32_t a = kc[e], b = kc[t];
+                kn[e] = a < b ? a : b;
+                xn[e] = xc[t];
+            }
+            __syncthreads();
+            int32_t* t1 = kc; kc = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
+        }
+        // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order)
+        auto ownfn = [&](uint32_t e) -> uint2 {
+            if (kc[e] != (int32_t)e) return make_uint2(0u, 0u);
+            // loop length by walking
+            uint32_t len = 0;
+            // decode (vertex, slot) of e: binary search over loff
+            uint32_t lo_v = 0, hi_v = n;
+            while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
+            int32_t start = (int32_t)lo_v, prev = start, curv = nbr[e];
+            len = 1;
+            while (curv != start && len <= H)
+            {
+                const uint32_t lc = loff[curv] - fr.mh_off;
+                const int32_t nx = face_next(nbr + lc, llen[curv], prev);
+                prev = curv; curv = nx; ++len;
+            }
+            return make_uint2(1u, len);
+        };
+        uint32_t nfaces = 0, lensum = 0;
+        scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
+        if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
+        {
+            const uint32_t nb = (H + SURTR_LANES - 1u) >> SURTR_LSH;
+            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            {
+                const uint32_t e = (b << SURTR_LSH) + lane_id();
+                uint2 c = make_uint2(0u, 0u);
+                if (e < H) c = ownfn(e);
+                const uint2 ex = wave_excl2(c);
+                if (e < H && c.x)
+                {
+                    const uint32_t fi = blk[b].x + ex.x, lo = blk[b].y + ex.y;
+                    uint32_t lo_v = 0, hi_v = n;
+                    while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
+                    int32_t* loop = loopbuf + lo;
+                    int32_t start = (int32_t)lo_v, prev = start, curv = nbr[e];
+                    uint32_t len = 1; loop[0] = start;
+                    while (curv != start && len < c.y)
+                    {
+                        loop[len++] = curv;
+                        const uint32_t lc = loff[curv] - fr.mh_off;
+                        const int32_t nx = face_next(nbr + lc, llen[curv], prev);
+                        prev = curv; curv = nx;
+                    }
+                    // 4. triangulate; room for 3*(len-2) indices at 3*(lo - 2*fi)
+                    uint32_t* out = tri + 3u * (lo - 2u * fi);
+                    fcnt[fi] = ear_clip_face(pos, loop, (int)len, eartmp + 3 * (size_t)lo, out);
+                    // remember where this face's triangles start
+                    xn[fi] = (int32_t)(3u * (lo - 2u * fi));
+                }
+            }
+        }
+        __syncthreads();
+        // 5. compact the triangle lists of the faces, in face order, into the index arena
+        auto cntfn = [&](uint32_t fi) -> uint2 { return make_uint2(fcnt[fi], 0u); };
+        uint32_t nidx = 0, dum = 0;
+        scan_blocks(nfaces, blk, sh, cntfn, nidx, dum);
+        if (tid == 0) sh.misc[0] = atomicAdd(&A.cursors[2], nidx);
+        __syncthreads();
+        const uint32_t ioff = sh.misc[0];
+        if ((uint64_t)ioff + nidx > A.capI) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY); continue; }
+        {
+            const uint32_t nb = (nfaces + SURTR_LANES - 1u) >> SURTR_LSH;
+            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            {
+                const uint32_t fi = (b << SURTR_LSH) + lane_id();
+                uint2 c = make_uint2(0u, 0u);
+                if (fi < nfaces) c = cntfn(fi);
+                const uint2 ex = wave_excl2(c);
+                if (fi < nfaces && c.x)
+                {
+                    const uint32_t* src = tri + (uint32_t)xn[fi];
+                    uint32_t* dst = A.idx + ioff + blk[b].x + ex.x;
+                    for (uint32_t q = 0; q < c.x; ++q) dst[q] = src[q];
+                }
+            }
+        }
+        if (tid == 0) { fr.idx_off = ioff; fr.idx_n = nidx; frags[f] = fr; }
+    }
+}
+
+// --------------------------------------------------------------- k_out_scan
+__global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ frags, uint2* __restrict__ blk,
+                                                       surtr_counts* __restrict__ counts, Arena A)
+{
+    __shared__ Shared sh;
+    const uint32_t nf = counts->n_frag;
+    const uint32_t nb = (nf + SURTR_LANES - 1u) >> SURTR_LSH;
+    uint32_t t0 = 0, t1 = 0;
+    auto f1 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].mv_n, frags[f].mh_n); };
+    scan_blocks(nf, blk, sh, f1, t0, t1);
+    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t f = (b << SURTR_LSH) + lane_id();
+        uint2 c = make_uint2(0u, 0u);
+        if (f < nf) c = f1(f);
+        const uint2 e = wave_excl2(c);
+        if (f < nf) { frags[f].o_mv = blk[b].x + e.x; frags[f].o_mh = blk[b].y + e.y; }
+    }
+    const uint32_t mv = t0, mh = t1;
+    __syncthreads();
+    auto f2 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].cv_n, frags[f].ch_n); };
+    scan_blocks(nf, blk, sh, f2, t0, t1);
+    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t f = (b << SURTR_LSH) + lane_id();
+        uint2 c = make_uint2(0u, 0u);
+        if (f < nf) c = f2(f);
+        const uint2 e = wave_excl2(c);
+        if (f < nf) { frags[f].o_cv = blk[b].x + e.x; frags[f].o_ch = blk[b].y + e.y; }
+    }
+    const uint32_t cv = t0, chh = t1;
+    __syncthreads();
+    auto f3 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].idx_n, 0u); };
+    scan_blocks(nf, blk, sh, f3, t0, t1);
+    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t f = (b << SURTR_LSH) + lane_id();
+        uint2 c = make_uint2(0u, 0u);
+        if (f < nf) c = f3(f);
+        const uint2 e = wave_excl2(c);
+        if (f < nf) frags[f].o_idx = blk[b].x + e.x;
+    }
+    if (threadIdx.x == 0)
+    {
+        counts->mesh_verts = mv; counts->mesh_nbrs = mh; counts->conv_verts = cv; counts->conv_nbrs = chh;
+        counts->n_idx = t0; counts->status = A.cursors[5];
+    }
+}
+
+// ------------------------------------------------------------------- k_pack
+// Blob layout (all sections 64-byte aligned, in this order):
+//   header  surtr_counts (32 B)
+//   frag_ids i32[3*nf] | mesh_vert_off u32[nf+1] | mesh_pos f32[3*mv] | mesh_nbr_off u32[mv+1] | mesh_nbr i32[mh]
+//   conv_vert_off u32[nf+1] | conv_pos f32[3*cv] | conv_nbr_off u32[cv+1] | conv_nbr i32[ch]
+//   vnc f32[9*mv] | idx_off u32[nf+1] | idx u32[ni]
+struct BlobLayout
+{
+    size_t ids, mvo, mpos, mno, mnbr, cvo, cpos, cno, cnbr, vnc, ioff, idx, total;
+};
+
+__host__ __device__ static BlobLayout blob_layout(const surtr_counts& c)
+{
+    BlobLayout L;
+    size_t at = 64;
+    auto put = [&](size_t bytes) { size_t r = at; at += (bytes + 63) & ~(size_t)63; return r; };
+    L.ids = put((size_t)c.n_frag * 12);
+    L.mvo = put(((size_t)c.n_frag + 1) * 4);
+    L.mpos = put((size_t)c.mesh_verts * 12);
+    L.mno = put(((size_t)c.mesh_verts + 1) * 4);
+    L.mnbr = put((size_t)c.mesh_nbrs * 4);
+    L.cvo = put(((size_t)c.n_frag + 1) * 4);
+    L.cpos = put((size_t)c.conv_verts * 12);
+    L.cno = put(((size_t)c.conv_verts + 1) * 4);
+    L.cnbr = put((size_t)c.conv_nbrs * 4);
+    L.vnc = put((size_t)c.mesh_verts * 36);
+    L.ioff = put(((size_t)c.n_frag + 1) * 4);
+    L.idx = put((size_t)c.n_idx * 4);
+    L.total = at;
+    return L;
+}
+
+__global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
+                                                   Arena A, char* __restrict__ blob, size_t capacity, uint32_t with_vnc)
+{
+    const surtr_counts c = *counts;
+    const BlobLayout L = blob_layout(c);
+    if (L.total > capacity) return;
+    const uint32_t nf = c.n_frag, tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0)
+    {
+        *(surtr_counts*)blob = c;
+        ((uint32_t*)(blob + L.mvo))[nf] = c.mesh_verts;
+        ((uint32_t*)(blob + L.mno))[c.mesh_verts] = c.mesh_nbrs;
+        ((uint32_t*)(blob + L.cvo))[nf] = c.conv_verts;
+        ((uint32_t*)(blob + L.cno))[c.conv_verts] = c.conv_nbrs;
+        ((uint32_t*)(blob + L.ioff))[nf] = c.n_idx;
+    }
+    for (uint32_t f = blockIdx.x; f < nf; f += gridDim.x)
+    {
+        const FragRec fr = frags[f];
+        if (tid == 0)
+        {
+            int32_t* ids = (int32_t*)(blob + L.ids);
+            ids[3 * f] = fr.cell; ids[3 * f + 1] = fr.piece; ids[3 * f + 2] = fr.island;
+            ((uint32_t*)(blob + L.mvo))[f] = fr.o_mv;
+            ((uint32_t*)(blob + L.cvo))[f] = fr.o_cv;
+            ((uint32_t*)(blob + L.ioff))[f] = fr.o_idx;
+        }
+        float* mpos = (float*)(blob + L.mpos) + 3 * (size_t)fr.o_mv;
+        const float* sp = A.pos + 3 * (size_t)fr.mv_off;
+        for (uint32_t i = tid; i < 3 * fr.mv_n; i += SURTR_WG) mpos[i] = sp[i];
+        uint32_t* mno = (uint32_t*)(blob + L.mno) + fr.o_mv;
+        for (uint32_t v = tid; v < fr.mv_n; v += SURTR_WG) mno[v] = fr.o_mh + (A.loff[fr.mv_off + v] - fr.mh_off);
+        int32_t* mnbr = (int32_t*)(blob + L.mnbr) + fr.o_mh;
+        for (uint32_t e = tid; e < fr.mh_n; e += SURTR_WG) mnbr[e] = A.nbr[fr.mh_off + e];
+        float* cpos = (float*)(blob + L.cpos) + 3 * (size_t)fr.o_cv;
+        const float* scp = A.pos + 3 * (size_t)fr.cv_off;
+        for (uint32_t i = tid; i < 3 * fr.cv_n; i += SURTR_WG) cpos[i] = scp[i];
+        uint32_t* cno = (uint32_t*)(blob + L.cno) + fr.o_cv;
+        for (uint32_t v = tid; v < fr.cv_n; v += SURTR_WG) cno[v] = fr.o_ch + (A.loff[fr.cv_off + v] - fr.ch_off);
+        int32_t* cnbr = (int32_t*)(blob + L.cnbr) + fr.o_ch;
+        for (uint32_t e = tid; e < fr.ch_n; e += SURTR_WG) cnbr[e] = A.nbr[fr.ch_off + e];
+        if (with_vnc)
+        {
+            // VertexNormalColor{pos, (0,0,0), (0.25,0.25,0.25)} (Src/Poly.cpp:690-694)
+            float* vnc = (float*)(blob + L.vnc) + 9 * (size_t)fr.o_mv;
+            for (uint32_t i = tid; i < 9 * fr.mv_n; i += SURTR_WG)
+            {
+                const uint32_t v = i / 9, k = i % 9;
+                vnc[i] = k < 3 ? sp[3 * v + k] : (k < 6 ? 0.f : 0.25f);
+            }
+        }
+        uint32_t* idx = (uint32_t*)(blob + L.idx) + fr.o_idx;
+        for (uint32_t e = tid; e < fr.idx_n; e += SURTR_WG) idx[e] = A.idx[fr.idx_off + e];
+    }
+}
+
+// ------------------------------------------------------------ single clip op
+__global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const float4* __restrict__ planes, uint32_t F,
+                                                          ScratchPool pool, float* opos, uint32_t* ooff, int32_t* onbr,
+                                                          uint32_t cap_v, uint32_t cap_h, uint32_t* result /* n, nh, status */)
+{
+    __shared__ Shared sh;
+    Scratch S = carve(pool, 0);
+    for (uint32_t k = threadIdx.x; k < F; k += SURTR_WG) sh.planes[k] = planes[k];
+    __syncthreads();
+    uint32_t n = 0, b = 0, nh = 0;
+    int err = clip_solid(in, F, S, sh, &n, &b, &nh);
+    __syncthreads();
+    if (err == 0 && (n > cap_v || nh > cap_h)) err = SURTR_E_CAPACITY;
+    if (err == 0)
+    {
+        const Buf& B = S.b[b];
+        for (uint32_t v = threadIdx.x; v < n; v += SURTR_WG)
+        {
+            opos[3 * v] = B.pos[3 * v]; opos[3 * v + 1] = B.pos[3 * v + 1]; opos[3 * v + 2] = B.pos[3 * v + 2];
+            ooff[v] = B.loff[v];
+        }
+        for (uint32_t e = threadIdx.x; e < nh; e += SURTR_WG) onbr[e] = B.nbr[e];
+        if (threadIdx.x == 0) ooff[n] = nh;
+    }
+    if (threadIdx.x == 0) { result[0] = n; result[1] = nh; result[2] = (uint32_t)err; }
+}
+
+// =================================================================== host ===
+struct surtr_ctx
+{
+    int device = 0;
+    uint32_t max_wg = 1024;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // pieces
+    uint32_t n_pieces = 0, vmax = 0, hmax = 0;
+    float *d_mpos = nullptr, *d_cpos = nullptr;
+    uint32_t *d_mloff = nullptr, *d_mllen = nullptr, *d_mvo = nullptr, *d_cloff = nullptr, *d_cllen = nullptr, *d_cvo = nullptr;
+    int32_t *d_mnbr = nullptr, *d_cnbr = nullptr;
+    uint8_t *d_mtri = nullptr, *d_ctri = nullptr;
+    uint64_t tot_mv = 0, tot_mh = 0;
+    // cells
+    uint32_t n_cells = 0, n_faces = 0;
+    float* d_v012 = nullptr; float4* d_planes = nullptr; uint32_t* d_plane_off = nullptr;
+    std::vector<uint32_t> h_plane_off;
+    bool planes_ready = false;
+    // scratch + arena
+    uint32_t user_cv = 0, user_ch = 0;
+    uint64_t user_av = 0, user_ah = 0, user_ai = 0;
+    ScratchPool pool{}; uint32_t n_wg = 0;
+    FaceScratch fs{}; uint2* d_blk = nullptr; uint32_t blk_per_wg = 0;
+    Arena arena{};
+    PairRec* d_pairs = nullptr; uint32_t cap_pairs = 0;
+    FragRec* d_frags = nullptr; uint32_t cap_frags = 0;
+    uint2* d_scanblk = nullptr; uint32_t cap_scanblk = 0;
+    surtr_counts* d_counts = nullptr;
+    uint8_t* d_outside = nullptr;
+    surtr_counts last{};
+    bool have_event = false; uint32_t last_flags = 0;
+    // staging for downloads
+    void* d_blob = nullptr; size_t blob_cap = 0;
+};
+
+#define HIPCHK(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return SURTR_E_HIP; } \
+    } while (0)
+
+static void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+extern "C" {
+
+const char* surtr_strerror(int code)
+{
+    switch (code)
+    {
+    case SURTR_OK: return "ok";
+    case SURTR_E_INVALID: return "invalid argument";
+    case SURTR_E_TOPOLOGY: return "topology error (asymmetric links or degree < 3)";
+    case SURTR_E_CAPACITY: return "capacity exceeded";
+    case SURTR_E_HIP: return "HIP runtime error";
+    case SURTR_E_STATE: return "call order violated";
+    case SURTR_E_NOGPU: return "no HIP device (the engine has no CPU fallback)";
+    default: return "unknown";
+    }
+}
+
+int surtr_create(int device, surtr_ctx** out)
+{
+    if (!out) return SURTR_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SURTR_E_NOGPU;
+    if (device < 0 || device >= n) return SURTR_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return SURTR_E_HIP;
+    surtr_ctx* ctx = new surtr_ctx;
+    ctx->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->max_wg = (uint32_t)prop.multiProcessorCount * 4u;
+    }
+    if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+    if (hipMalloc((void**)&ctx->arena.cursors, 64) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+    *out = ctx;
+    return SURTR_OK;
+}
+
+void surtr_destroy(surtr_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    free_dev(ctx->d_mpos); free_dev(ctx->d_cpos); free_dev(ctx->d_mloff); free_dev(ctx->d_mllen); free_dev(ctx->d_mvo);
+    free_dev(ctx->d_cloff); free_dev(ctx->d_cllen); free_dev(ctx->d_cvo); free_dev(ctx->d_mnbr); free_dev(ctx->d_cnbr);
+    free_dev(ctx->d_mtri); free_dev(ctx->d_ctri);
+    free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
+    free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
+    free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
+    free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
+    free_dev(ctx->d_outside); free_dev(ctx->d_blob);
+    delete ctx;
+}
+
+const char* surtr_last_error(surtr_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int surtr_set_stream(surtr_ctx* ctx, void* s)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    ctx->stream = (hipStream_t)s;
+    return SURTR_OK;
+}
+
+int surtr_set_scratch(surtr_ctx* ctx, uint32_t mv, uint32_t mh)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    ctx->user_cv = mv; ctx->user_ch = mh;
+    free_dev(ctx->pool.base); ctx->pool.base = nullptr;
+    return SURTR_OK;
+}
+
+int surtr_set_arena(surtr_ctx* ctx, uint64_t v, uint64_t h, uint64_t i)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    ctx->user_av = v; ctx->user_ah = h; ctx->user_ai = i;
+    free_dev(ctx->arena.pos); ctx->arena.pos = nullptr;
+    return SURTR_OK;
+}
+
+// Validates one solid: indices in range, degree >= 3, symmetric links (Src/Poly.cpp:253-260).
+static int check_solid(uint32_t nv, const uint32_t* off, const int32_t* nbr)
+{
+    for (uint32_t v = 0; v < nv; ++v)
+    {
+        if (off[v + 1] < off[v]) return SURTR_E_INVALID;
+        const uint32_t deg = off[v + 1] - off[v];
+        if (deg < 3) return SURTR_E_TOPOLOGY;
+        for (uint32_t j = off[v]; j < off[v + 1]; ++j)
+        {
+            const int32_t u = nbr[j];
+            if (u < 0 || (uint32_t)u >= nv || (uint32_t)u == v) return SURTR_E_TOPOLOGY;
+            bool back = false;
+            for (uint32_t q = off[u]; q < off[u + 1]; ++q) if (nbr[q] == (int32_t)v) { back = true; break; }
+            if (!back) return SURTR_E_TOPOLOGY;
+        }
+    }
+    return SURTR_OK;
+}
+
+static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const float* pos, const uint32_t* off, const int32_t* nbr,
+                      float** d_pos, uint32_t** d_loff, uint32_t** d_llen, int32_t** d_nbr, uint32_t** d_vo, uint8_t** d_tri,
+                      uint32_t& vmax, uint32_t& hmax, uint64_t& totv, uint64_t& toth)
+{
+    const uint32_t V = vo[n];
+    const uint32_t H = off[V];
+    std::vector<uint32_t> llen(V);
+    for (uint32_t p = 0; p < n; ++p)
+    {
+        const uint32_t a = vo[p], b = vo[p + 1];
+        if (b < a || b - a < 4) return SURTR_E_INVALID;
+        // local CSR view of this solid
+        std::vector<uint32_t> loc(b - a + 1);
+        for (uint32_t v = a; v <= b; ++v) loc[v - a] = off[v] - off[a];
+        int rc = check_solid(b - a, loc.data(), nbr + off[a]);
+        if (rc) return rc;
+        vmax = std::max(vmax, b - a);
+        hmax = std::max(hmax, off[b] - off[a]);
+    }
+    for (uint32_t v = 0; v < V; ++v) llen[v] = off[v + 1] - off[v];
+    // tri[v] = 1 when every face around v is a triangle (then the 1-ring holds all vertices of its faces)
+    std::vector<uint8_t> tri(V, 1);
+    for (uint32_t p = 0; p < n; ++p)
+    {
+        const uint32_t a = vo[p], b = vo[p + 1];
+        auto ring = [&](int32_t lv) { return nbr + off[a + lv]; };
+        auto rlen = [&](int32_t lv) { return off[a + lv + 1] - off[a + lv]; };
+        auto prevof = [&](int32_t lv, int32_t who) {
+            const int32_t* r = ring(lv); const uint32_t len = rlen(lv);
+            uint32_t k = 0;
+            while (k < len && r[k] != who) ++k;
+            return k == 0 ? r[len - 1] : r[k - 1];
+        };
+        for (uint32_t v = a; v < b; ++v)
+        {
+            const int32_t lv = (int32_t)(v - a);
+            for (uint32_t j = off[v]; j < off[v + 1]; ++j)
+            {
+                const int32_t x = nbr[j];
+                const int32_t y = prevof(x, lv);
+                if (y == lv || prevof(y, x) != lv) { tri[v] = 0; break; }
+            }
+        }
+    }
+    free_dev(*d_pos); free_dev(*d_tri); *d_tri = nullptr; free_dev(*d_loff); free_dev(*d_llen); free_dev(*d_nbr); free_dev(*d_vo);
+    *d_pos = nullptr; *d_loff = nullptr; *d_llen = nullptr; *d_nbr = nullptr; *d_vo = nullptr;
+    HIPCHK(hipMalloc((void**)d_pos, std::max<size_t>(16, (size_t)V * 12)));
+    HIPCHK(hipMalloc((void**)d_loff, std::max<size_t>(16, (size_t)(V + 1) * 4)));
+    HIPCHK(hipMalloc((void**)d_llen, std::max<size_t>(16, (size_t)V * 4)));
+    HIPCHK(hipMalloc((void**)d_nbr, std::max<size_t>(16, (size_t)H * 4)));
+    HIPCHK(hipMalloc((void**)d_vo, (size_t)(n + 1) * 4));
+    HIPCHK(hipMemcpy(*d_pos, pos, (size_t)V * 12, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_loff, off, (size_t)(V + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_llen, llen.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*d_vo, vo, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)d_tri, std::max<size_t>(16, (size_t)V)));
+    HIPCHK(hipMemcpy(*d_tri, tri.data(), (size_t)V, hipMemcpyHostToDevice));
+    totv = V; toth = H;
+    return SURTR_OK;
+}
+
+int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const float* mpos, const uint32_t* moff,
+                        const int32_t* mnbr, const uint32_t* cvo, const float* cpos, const uint32_t* coff, const int32_t* cnbr)
+{
+    if (!ctx || n == 0 || !mvo || !mpos || !moff || !mnbr || !cvo || !cpos || !coff || !cnbr) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    uint32_t vmax = 0, hmax = 0; uint64_t tv = 0, th = 0, cv = 0, chh = 0;
+    int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri,
+                        vmax, hmax, tv, th);
+    if (rc) return rc;
+    rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri,
+                    vmax, hmax, cv, chh);
+    if (rc) return rc;
+    ctx->n_pieces = n; ctx->vmax = vmax; ctx->hmax = hmax; ctx->tot_mv = tv; ctx->tot_mh = th;
+    free_dev(ctx->pool.base); ctx->pool.base = nullptr;      // re-size scratch lazily
+    free_dev(ctx->d_outside); ctx->d_outside = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_outside, std::max<uint32_t>(n, 16)));
+    ctx->have_event = false;
+    return SURTR_OK;
+}
+
+int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_off, const float* v012)
+{
+    if (!ctx || n_cells == 0 || !face_off || !v012) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t nf = face_off[n_cells];
+    for (uint32_t c = 0; c < n_cells; ++c)
+        if (face_off[c + 1] < face_off[c] || face_off[c + 1] - face_off[c] > SURTR_MAXF) return SURTR_E_INVALID;
+    free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
+    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_v012, std::max<size_t>(16, (size_t)nf * 36)));
+    HIPCHK(hipMalloc((void**)&ctx->d_planes, std::max<size_t>(16, (size_t)nf * 16)));
+    HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(n_cells + 1) * 4));
+    HIPCHK(hipMemcpy(ctx->d_v012, v012, (size_t)nf * 36, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_plane_off, face_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
+    ctx->h_plane_off.assign(face_off, face_off + n_cells + 1);
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = false;
+    return SURTR_OK;
+}
+
+int surtr_place_cells(surtr_ctx* ctx, const float scale[3], const float translate[3])
+{
+    if (!ctx || !scale || !translate) return SURTR_E_INVALID;
+    if (!ctx->d_v012) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t nf = ctx->n_faces;
+    if (nf)
+        hipLaunchKernelGGL(k_place_cells, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, nf, ctx->d_v012, scale[0], scale[1],
+                           scale[2], translate[0], translate[1], translate[2], ctx->d_planes);
+    HIPCHK(hipGetLastError());
+    ctx->planes_ready = true;
+    return SURTR_OK;
+}
+
+int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_off, const float* planes)
+{
+    if (!ctx || n_cells == 0 || !plane_off || !planes) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t nf = plane_off[n_cells];
+    for (uint32_t c = 0; c < n_cells; ++c)
+        if (plane_off[c + 1] < plane_off[c] || plane_off[c + 1] - plane_off[c] > SURTR_MAXF) return SURTR_E_INVALID;
+    free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
+    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr;
+    HIPCHK(hipMalloc((void**)&ctx->d_planes, std::max<size_t>(16, (size_t)nf * 16)));
+    HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(n_cells + 1) * 4));
+    HIPCHK(hipMemcpy(ctx->d_planes, planes, (size_t)nf * 16, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(ctx->d_plane_off, plane_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
+    ctx->h_plane_off.assign(plane_off, plane_off + n_cells + 1);
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = true;
+    return SURTR_OK;
+}
+
+static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint32_t n_wg)
+{
+    uint32_t CV = ctx->user_cv ? ctx->user_cv : need_v + need_v / 2 + 1024;
+    uint32_t CH = ctx->user_ch ? ctx->user_ch : 2 * need_h + 8192;
+    const uint32_t VMAX = need_v;
+    const uint32_t NB = (std::max(CV, VMAX) + SURTR_LANES - 1) / SURTR_LANES + 4;
+    if (ctx->pool.base && ctx->pool.CV >= CV && ctx->pool.CH >= CH && ctx->pool.VMAX >= VMAX && ctx->n_wg >= n_wg) return SURTR_OK;
+    free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    ctx->pool.base = nullptr; ctx->fs.base = nullptr; ctx->d_blk = nullptr;
+    ctx->pool.CV = CV; ctx->pool.CH = CH; ctx->pool.VMAX = VMAX; ctx->pool.NB = NB;
+    ctx->pool.per_wg = scratch_bytes_per_wg(CV, CH, VMAX, NB);
+    ctx->n_wg = n_wg;
+    HIPCHK(hipMalloc((void**)&ctx->pool.base, ctx->pool.per_wg * n_wg));
+    ctx->fs.HF = CH / 2;
+    ctx->fs.per_wg = (size_t)12 * ctx->fs.HF;
+    HIPCHK(hipMalloc((void**)&ctx->fs.base, ctx->fs.per_wg * 4 * n_wg));
+    ctx->blk_per_wg = ctx->fs.HF / SURTR_LANES + 4;
+    HIPCHK(hipMalloc((void**)&ctx->d_blk, (size_t)ctx->blk_per_wg * 8 * n_wg));
+    return SURTR_OK;
+}
+
+static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
+{
+    // Result sizes are data dependent; the default reserves the whole input once per 8 pairs plus slack.
+    uint64_t av = ctx->user_av ? ctx->user_av : std::max<uint64_t>((uint64_t)ctx->vmax * 8 + (uint64_t)n_pairs * 256, 1u << 16);
+    uint64_t ah = ctx->user_ah ? ctx->user_ah : std::max<uint64_t>((uint64_t)ctx->hmax * 8 + (uint64_t)n_pairs * 1024, 1u << 18);
+    uint64_t ai = ctx->user_ai ? ctx->user_ai : ah * 2;
+    av = std::min<uint64_t>(av, 0xFFFFFFF0ull); ah = std::min<uint64_t>(ah, 0xFFFFFFF0ull); ai = std::min<uint64_t>(ai, 0xFFFFFFF0ull);
+    const uint32_t capIsl = (uint32_t)std::min<uint64_t>((uint64_t)n_pairs * 4 + 1024, 0x7FFFFFFFull);
+    if (!(ctx->arena.pos && ctx->arena.capV >= av && ctx->arena.capH >= ah && ctx->arena.capI >= ai && ctx->arena.capIsl >= capIsl))
+    {
+        free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
+        free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->d_frags);
+        ctx->arena.pos = nullptr; ctx->arena.loff = nullptr; ctx->arena.llen = nullptr; ctx->arena.nbr = nullptr;
+        ctx->arena.idx = nullptr; ctx->arena.isl = nullptr; ctx->d_frags = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->arena.pos, av * 12));
+        HIPCHK(hipMalloc((void**)&ctx->arena.loff, av * 4));
+        HIPCHK(hipMalloc((void**)&ctx->arena.llen, av * 4));
+        HIPCHK(hipMalloc((void**)&ctx->arena.nbr, ah * 4));
+        HIPCHK(hipMalloc((void**)&ctx->arena.idx, ai * 4));
+        HIPCHK(hipMalloc((void**)&ctx->arena.isl, (size_t)capIsl * 8));
+        HIPCHK(hipMalloc((void**)&ctx->d_frags, (size_t)capIsl * sizeof(FragRec)));
+        ctx->arena.capV = (uint32_t)av; ctx->arena.capH = (uint32_t)ah; ctx->arena.capI = (uint32_t)ai; ctx->arena.capIsl = capIsl;
+        ctx->cap_frags = capIsl;
+    }
+    if (ctx->cap_pairs < n_pairs)
+    {
+        free_dev(ctx->d_pairs); ctx->d_pairs = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->d_pairs, (size_t)n_pairs * sizeof(PairRec)));
+        ctx->cap_pairs = n_pairs;
+    }
+    const uint32_t need_blk = std::max(n_pairs, ctx->cap_frags) / SURTR_LANES + 4;
+    if (ctx->cap_scanblk < need_blk)
+    {
+        free_dev(ctx->d_scanblk); ctx->d_scanblk = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->d_scanblk, (size_t)need_blk * 8));
+        ctx->cap_scanblk = need_blk;
+    }
+    return SURTR_OK;
+}
+
+int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end, const uint8_t* outside, uint32_t flags)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    if (!ctx->n_pieces || !ctx->planes_ready) return SURTR_E_STATE;
+    if (cell_end > ctx->n_cells || cell_begin > cell_end) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t n_pairs = (cell_end - cell_begin) * ctx->n_pieces;
+    const uint32_t max_wg = ctx->max_wg;
+    const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
+    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(n_wg, ctx->n_wg));
+    if (rc) return rc;
+    rc = ensure_arena(ctx, std::max(n_pairs, 1u));
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 64, st));
+    HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
+    const uint8_t* d_out = nullptr;
+    if (outside)
+    {
+        HIPCHK(hipMemcpyAsync(ctx->d_outside, outside, ctx->n_pieces, hipMemcpyHostToDevice, st));
+        d_out = ctx->d_outside;
+    }
+    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri,
+             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->n_pieces};
+    if (n_pairs)
+        hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           d_out, ctx->pool, ctx->arena, ctx->d_pairs);
+    hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
+                       ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts);
+    if (flags & SURTR_EVT_REFIT)
+        hipLaunchKernelGGL(k_refit, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool, ctx->arena);
+    if (flags & SURTR_EVT_RENDER)
+        hipLaunchKernelGGL(k_faces, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
+                           ctx->blk_per_wg, ctx->arena);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    HIPCHK(hipGetLastError());
+    ctx->have_event = true; ctx->last_flags = flags;
+    return SURTR_OK;
+}
+
+int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts)
+{
+    if (!ctx || !counts) return SURTR_E_INVALID;
+    if (!ctx->have_event) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipMemcpyAsync(&ctx->last, ctx->d_counts, sizeof(surtr_counts), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *counts = ctx->last;
+    return ctx->last.status ? (int)ctx->last.status : SURTR_OK;
+}
+
+int surtr_fracture_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end, const uint8_t* outside, uint32_t flags,
+                         surtr_counts* counts)
+{
+    int rc = surtr_fracture_event_async(ctx, cell_begin, cell_end, outside, flags);
+    if (rc) return rc;
+    surtr_counts c;
+    rc = surtr_event_counts(ctx, &c);
+    if (counts) *counts = c;
+    return rc;
+}
+
+size_t surtr_event_blob_bytes(const surtr_counts* counts)
+{
+    if (!counts) return 0;
+    return blob_layout(*counts).total;
+}
+
+int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
+{
+    if (!ctx || !dev_blob) return SURTR_E_INVALID;
+    if (!ctx->have_event) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    // capacity is checked on the device against the counts it holds; the host check uses the last fetched counts if any
+    const uint32_t grid = std::max(1u, std::min(ctx->cap_frags, 2048u));
+    hipLaunchKernelGGL(k_pack, dim3(grid), dim3(SURTR_WG), 0, ctx->stream, ctx->d_frags, ctx->d_counts, ctx->arena, (char*)dev_blob,
+                       capacity, (ctx->last_flags & SURTR_EVT_RENDER) ? 1u : 0u);
+    HIPCHK(hipGetLastError());
+    return SURTR_OK;
+}
+
+int surtr_blob_unpack_host(const void* blob, size_t bytes, surtr_counts* counts, surtr_fragments* out)
+{
+    if (!blob || bytes < 64) return SURTR_E_INVALID;
+    surtr_counts c;
+    memcpy(&c, blob, sizeof(c));
+    const BlobLayout L = blob_layout(c);
+    if (L.total > bytes) return SURTR_E_CAPACITY;
+    if (counts) *counts = c;
+    if (!out) return SURTR_OK;
+    const char* b = (const char*)blob;
+    auto cp = [&](void* dst, size_t off, size_t n) { if (dst && n) memcpy(dst, b + off, n); };
+    cp(out->frag_ids, L.ids, (size_t)c.n_frag * 12);
+    cp(out->mesh_vert_off, L.mvo, ((size_t)c.n_frag + 1) * 4);
+    cp(out->mesh_pos, L.mpos, (size_t)c.mesh_verts * 12);
+    cp(out->mesh_nbr_off, L.mno, ((size_t)c.mesh_verts + 1) * 4);
+    cp(out->mesh_nbr, L.mnbr, (size_t)c.mesh_nbrs * 4);
+    cp(out->conv_vert_off, L.cvo, ((size_t)c.n_frag + 1) * 4);
+    cp(out->conv_pos, L.cpos, (size_t)c.conv_verts * 12);
+    cp(out->conv_nbr_off, L.cno, ((size_t)c.conv_verts + 1) * 4);
+    cp(out->conv_nbr, L.cnbr, (size_t)c.conv_nbrs * 4);
+    cp(out->vnc, L.vnc, (size_t)c.mesh_verts * 36);
+    cp(out->idx_off, L.ioff, ((size_t)c.n_frag + 1) * 4);
+    cp(out->idx, L.idx, (size_t)c.n_idx * 4);
+    return SURTR_OK;
+}
+
+int surtr_event_download(surtr_ctx* ctx, surtr_fragments* out)
+{
+    if (!ctx || !out) return SURTR_E_INVALID;
+    surtr_counts c;
+    int rc = surtr_event_counts(ctx, &c);
+    if (rc) return rc;
+    const size_t need = blob_layout(c).total;
+    if (ctx->blob_cap < need)
+    {
+        free_dev(ctx->d_blob); ctx->d_blob = nullptr;
+        HIPCHK(hipMalloc(&ctx->d_blob, need));
+        ctx->blob_cap = need;
+    }
+    rc = surtr_event_pack_dev(ctx, ctx->d_blob, ctx->blob_cap);
+    if (rc) return rc;
+    std::vector<char> host(need);
+    HIPCHK(hipMemcpyAsync(host.data(), ctx->d_blob, need, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return surtr_blob_unpack_host(host.data(), need, nullptr, out);
+}
+
+int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* off, const int32_t* nbr,
+                          uint32_t n_planes, const float* planes, uint32_t* out_nv, uint32_t* out_nh, float* out_pos,
+                          uint32_t* out_off, int32_t* out_nbr)
+{
+    if (!ctx || !pos || !off || !nbr || !planes || nv < 4 || n_planes > SURTR_MAXF) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int rc = check_solid(nv, off, nbr);
+    if (rc) return rc;
+    const uint32_t H = off[nv];
+    rc = ensure_scratch(ctx, std::max(nv, ctx->vmax), std::max(H, ctx->hmax), std::max(1u, ctx->n_wg));
+    if (rc) return rc;
+    const uint32_t capv = ctx->pool.CV, caph = ctx->pool.CH;
+    float *d_pos = nullptr, *d_opos = nullptr; uint32_t *d_loff = nullptr, *d_llen = nullptr, *d_ooff = nullptr, *d_res = nullptr;
+    int32_t *d_nbr = nullptr, *d_onbr = nullptr; float4* d_pl = nullptr;
+    std::vector<uint32_t> llen(nv);
+    for (uint32_t v = 0; v < nv; ++v) llen[v] = off[v + 1] - off[v];
+    auto cleanup = [&]() { free_dev(d_pos); free_dev(d_opos); free_dev(d_loff); free_dev(d_llen); free_dev(d_ooff); free_dev(d_res);
+                           free_dev(d_nbr); free_dev(d_onbr); free_dev(d_pl); };
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx->err = hipGetErrorString(e_); cleanup(); return SURTR_E_HIP; } } while (0)
+    CK(hipMalloc((void**)&d_pos, (size_t)nv * 12)); CK(hipMalloc((void**)&d_loff, (size_t)(nv + 1) * 4));
+    CK(hipMalloc((void**)&d_llen, (size_t)nv * 4)); CK(hipMalloc((void**)&d_nbr, std::max<size_t>(16, (size_t)H * 4)));
+    CK(hipMalloc((void**)&d_pl, std::max<size_t>(16, (size_t)n_planes * 16)));
+    CK(hipMalloc((void**)&d_opos, (size_t)capv * 12)); CK(hipMalloc((void**)&d_ooff, (size_t)(capv + 1) * 4));
+    CK(hipMalloc((void**)&d_onbr, (size_t)caph * 4)); CK(hipMalloc((void**)&d_res, 16));
+    CK(hipMemcpy(d_pos, pos, (size_t)nv * 12, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_loff, off, (size_t)(nv + 1) * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_llen, llen.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
+    if (n_planes) CK(hipMemcpy(d_pl, planes, (size_t)n_planes * 16, hipMemcpyHostToDevice));
+    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr};
+    hipLaunchKernelGGL(k_clip_single, dim3(1), dim3(SURTR_WG), 0, ctx->stream, in, d_pl, n_planes, ctx->pool, d_opos, d_ooff, d_onbr,
+                       capv, caph, d_res);
+    CK(hipGetLastError());
+    uint32_t res[3] = {0, 0, 0};
+    CK(hipMemcpyAsync(res, d_res, 12, hipMemcpyDeviceToHost, ctx->stream));
+    CK(hipStreamSynchronize(ctx->stream));
+    if (res[2] == 0)
+    {
+        if (out_nv) *out_nv = res[0];
+        if (out_nh) *out_nh = res[1];
+        if (out_pos && res[0]) CK(hipMemcpy(out_pos, d_opos, (size_t)res[0] * 12, hipMemcpyDeviceToHost));
+        if (out_off) CK(hipMemcpy(out_off, d_ooff, (size_t)(res[0] + 1) * 4, hipMemcpyDeviceToHost));
+        if (out_nbr && res[1]) CK(hipMemcpy(out_nbr, d_onbr, (size_t)res[1] * 4, hipMemcpyDeviceToHost));
+        if (out_off && res[0] == 0) out_off[0] = 0;
+    }
+#undef CK
+    cleanup();
+    return (int)res[2];
+}
+
+} // extern "C"

@@ -1,0 +1,279 @@
+"""ctypes binding of libsurtr_hip.so (include/surtr_hip.h) for tests and bench.
+
+This is plumbing only: numpy arrays in, numpy arrays out, every call goes
+through the C ABI.  There is no CPU fallback -- if the shared library or a HIP
+device is missing the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+OK, E_INVALID, E_TOPOLOGY, E_CAPACITY, E_HIP, E_STATE, E_NOGPU = range(7)
+EVT_REFIT, EVT_RENDER = 1, 2
+
+
+class SurtrError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        RuntimeError.__init__(self, "surtr error %d: %s %s" % (code, _strerror(code), msg))
+
+
+class Counts(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in
+                ("n_frag", "mesh_verts", "mesh_nbrs", "conv_verts", "conv_nbrs", "n_idx", "n_pairs", "status")]
+
+
+class Fragments(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in
+                ("frag_ids", "mesh_vert_off", "mesh_pos", "mesh_nbr_off", "mesh_nbr", "conv_vert_off", "conv_pos",
+                 "conv_nbr_off", "conv_nbr", "vnc", "idx_off", "idx")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsurtr_hip.so")
+
+
+def _configure(L):
+    L.surtr_strerror.restype = ctypes.c_char_p
+    L.surtr_last_error.restype = ctypes.c_char_p
+    L.surtr_last_error.argtypes = [ctypes.c_void_p]
+    L.surtr_event_blob_bytes.restype = ctypes.c_size_t
+    L.surtr_destroy.argtypes = [ctypes.c_void_p]
+    L.surtr_destroy.restype = None
+    return L
+
+
+def _use_library_for_tests(path):
+    """tests/ only: bind the single-lane CPU emulation of the kernels (tests/emul/libsurtr_emul.so)
+    so kernel logic can be checked without a GPU.  Never called by product code."""
+    global _LIB
+    _LIB = _configure(ctypes.CDLL(path)) if path else None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(lib_path()):
+            raise ImportError("libsurtr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = _configure(ctypes.CDLL(lib_path()))
+        _LIB = L
+    return _LIB
+
+
+def _strerror(code):
+    try:
+        return lib().surtr_strerror(ctypes.c_int(code)).decode()
+    except Exception:
+        return "?"
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def pack_solids(solids):
+    """list of {'pos','off','nbr'} -> (vert_off, pos, nbr_off (global), nbr)"""
+    vo = [0]
+    pos, off, nbr = [], [np.zeros(1, np.int64)], []
+    base = 0
+    for s in solids:
+        p = np.ascontiguousarray(s["pos"], np.float32).reshape(-1, 3)
+        o = np.asarray(s["off"], np.int64)
+        pos.append(p)
+        off.append(o[1:] + base)
+        base += int(o[-1])
+        nbr.append(np.asarray(s["nbr"], np.int32))
+        vo.append(vo[-1] + p.shape[0])
+    return (np.asarray(vo, np.uint32), np.ascontiguousarray(np.concatenate(pos), np.float32),
+            np.concatenate(off).astype(np.uint32), np.ascontiguousarray(np.concatenate(nbr), np.int32))
+
+
+class Engine:
+    """One context per GPU (surtr_create / surtr_destroy)."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = ctypes.c_void_p()
+        rc = lib().surtr_create(ctypes.c_int(device), ctypes.byref(self._h))
+        if rc:
+            raise SurtrError(rc)
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._h:
+            lib().surtr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise SurtrError(rc, lib().surtr_last_error(self._h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._ck(lib().surtr_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def set_scratch(self, max_verts, max_nbrs):
+        self._ck(lib().surtr_set_scratch(self._h, ctypes.c_uint32(max_verts), ctypes.c_uint32(max_nbrs)))
+
+    def set_arena(self, verts, nbrs, idx):
+        self._ck(lib().surtr_set_arena(self._h, ctypes.c_uint64(verts), ctypes.c_uint64(nbrs), ctypes.c_uint64(idx)))
+
+    def upload_pieces(self, meshes, convexes):
+        assert len(meshes) == len(convexes)
+        m = pack_solids(meshes)
+        c = pack_solids(convexes)
+        self._ck(lib().surtr_upload_pieces(self._h, ctypes.c_uint32(len(meshes)), _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]),
+                                           _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3])))
+
+    def upload_pattern(self, face_off, v012):
+        fo = np.ascontiguousarray(face_off, np.uint32)
+        v = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)
+        assert v.shape[0] == fo[-1]
+        self._ck(lib().surtr_upload_pattern(self._h, ctypes.c_uint32(fo.shape[0] - 1), _p(fo), _p(v)))
+
+    def place_cells(self, scale, translate):
+        s = np.ascontiguousarray(scale, np.float32)
+        t = np.ascontiguousarray(translate, np.float32)
+        self._ck(lib().surtr_place_cells(self._h, _p(s), _p(t)))
+
+    def upload_planes(self, plane_off, planes):
+        po = np.ascontiguousarray(plane_off, np.uint32)
+        pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+        self._ck(lib().surtr_upload_planes(self._h, ctypes.c_uint32(po.shape[0] - 1), _p(po), _p(pl)))
+
+    def fracture_event(self, cell_begin, cell_end, outside=None, flags=EVT_REFIT | EVT_RENDER):
+        c = Counts()
+        om = None if outside is None else np.ascontiguousarray(outside, np.uint8)
+        self._ck(lib().surtr_fracture_event(self._h, ctypes.c_uint32(cell_begin), ctypes.c_uint32(cell_end), _p(om),
+                                            ctypes.c_uint32(flags), ctypes.byref(c)))
+        return c
+
+    def fracture_event_async(self, cell_begin, cell_end, outside=None, flags=EVT_REFIT | EVT_RENDER):
+        om = None if outside is None else np.ascontiguousarray(outside, np.uint8)
+        self._ck(lib().surtr_fracture_event_async(self._h, ctypes.c_uint32(cell_begin), ctypes.c_uint32(cell_end), _p(om),
+                                                  ctypes.c_uint32(flags)))
+
+    def event_counts(self):
+        c = Counts()
+        self._ck(lib().surtr_event_counts(self._h, ctypes.byref(c)))
+        return c
+
+    def pack_dev(self, dev_ptr, capacity):
+        self._ck(lib().surtr_event_pack_dev(self._h, ctypes.c_void_p(dev_ptr), ctypes.c_size_t(capacity)))
+
+    def download(self):
+        c = self.event_counts()
+        out = alloc_fragments(c)
+        fr = _frag_struct(out)
+        self._ck(lib().surtr_event_download(self._h, ctypes.byref(fr)))
+        return shape_fragments(out)
+
+    def clip_polyhedron(self, solid, planes):
+        pos = np.ascontiguousarray(solid["pos"], np.float32).reshape(-1, 3)
+        off = np.ascontiguousarray(solid["off"], np.uint32)
+        nbr = np.ascontiguousarray(solid["nbr"], np.int32)
+        pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+        nv = ctypes.c_uint32()
+        nh = ctypes.c_uint32()
+        args = [self._h, ctypes.c_uint32(pos.shape[0]), _p(pos), _p(off), _p(nbr), ctypes.c_uint32(pl.shape[0]), _p(pl)]
+        self._ck(lib().surtr_clip_polyhedron(*args, ctypes.byref(nv), ctypes.byref(nh), None, None, None))
+        opos = np.zeros((nv.value, 3), np.float32)
+        ooff = np.zeros(nv.value + 1, np.uint32)
+        onbr = np.zeros(nh.value, np.int32)
+        self._ck(lib().surtr_clip_polyhedron(*args, ctypes.byref(nv), ctypes.byref(nh), _p(opos), _p(ooff), _p(onbr)))
+        return {"pos": opos, "off": ooff, "nbr": onbr}
+
+
+_FIELDS = [("frag_ids", np.int32, lambda c: 3 * c.n_frag), ("mesh_vert_off", np.uint32, lambda c: c.n_frag + 1),
+           ("mesh_pos", np.float32, lambda c: 3 * c.mesh_verts), ("mesh_nbr_off", np.uint32, lambda c: c.mesh_verts + 1),
+           ("mesh_nbr", np.int32, lambda c: c.mesh_nbrs), ("conv_vert_off", np.uint32, lambda c: c.n_frag + 1),
+           ("conv_pos", np.float32, lambda c: 3 * c.conv_verts), ("conv_nbr_off", np.uint32, lambda c: c.conv_verts + 1),
+           ("conv_nbr", np.int32, lambda c: c.conv_nbrs), ("vnc", np.float32, lambda c: 9 * c.mesh_verts),
+           ("idx_off", np.uint32, lambda c: c.n_frag + 1), ("idx", np.uint32, lambda c: c.n_idx)]
+
+
+def alloc_fragments(c):
+    return {name: np.zeros(max(int(size(c)), 0), dt) for name, dt, size in _FIELDS}
+
+
+def _frag_struct(out):
+    fr = Fragments()
+    for name, _, _ in _FIELDS:
+        setattr(fr, name, out[name].ctypes.data)
+    return fr
+
+
+def shape_fragments(out):
+    out = dict(out)
+    out["frag_ids"] = out["frag_ids"].reshape(-1, 3)
+    out["mesh_pos"] = out["mesh_pos"].reshape(-1, 3)
+    out["conv_pos"] = out["conv_pos"].reshape(-1, 3)
+    out["vnc"] = out["vnc"].reshape(-1, 9)
+    return out
+
+
+def unpack_blob(host_blob):
+    """host_blob: contiguous uint8 numpy array holding one packed fragment blob."""
+    b = np.ascontiguousarray(host_blob, np.uint8)
+    c = Counts()
+    rc = lib().surtr_blob_unpack_host(_p(b), ctypes.c_size_t(b.nbytes), ctypes.byref(c), None)
+    if rc:
+        raise SurtrError(rc)
+    out = alloc_fragments(c)
+    fr = _frag_struct(out)
+    rc = lib().surtr_blob_unpack_host(_p(b), ctypes.c_size_t(b.nbytes), ctypes.byref(c), ctypes.byref(fr))
+    if rc:
+        raise SurtrError(rc)
+    return c, shape_fragments(out)
+
+
+def blob_bytes(counts):
+    return int(lib().surtr_event_blob_bytes(ctypes.byref(counts)))
+
+
+def neighbors_from_mesh(pos, tris):
+    """Poly::ExtractNeighborFromMesh through the C ABI (host helper)."""
+    pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+    tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 3)
+    off = np.zeros(pos.shape[0] + 1, np.uint32)
+    nbr = np.zeros(6 * tris.shape[0], np.int32)
+    rc = lib().surtr_neighbors_from_mesh(ctypes.c_uint32(pos.shape[0]), ctypes.c_uint32(tris.shape[0]), _p(tris), _p(off), _p(nbr))
+    if rc:
+        raise SurtrError(rc)
+    return {"pos": pos, "off": off, "nbr": nbr[:off[-1]].copy()}
+
+
+def voronoi_cells(seeds):
+    s = np.ascontiguousarray(seeds, np.float64).reshape(-1, 3)
+    nf = ctypes.c_uint32()
+    nfv = ctypes.c_uint32()
+    rc = lib().surtr_voronoi_cells(ctypes.c_uint32(s.shape[0]), _p(s), ctypes.byref(nf), ctypes.byref(nfv), None, None, None, None)
+    if rc:
+        raise SurtrError(rc)
+    cfo = np.zeros(s.shape[0] + 1, np.uint32)
+    gen = np.zeros(nf.value, np.int32)
+    fvo = np.zeros(nf.value + 1, np.uint32)
+    verts = np.zeros((nfv.value, 3), np.float64)
+    rc = lib().surtr_voronoi_cells(ctypes.c_uint32(s.shape[0]), _p(s), ctypes.byref(nf), ctypes.byref(nfv), _p(cfo), _p(gen), _p(fvo),
+                                   _p(verts))
+    if rc:
+        raise SurtrError(rc)
+    return {"cell_face_off": cfo, "face_gen": gen, "face_vert_off": fvo, "verts": verts}
+
+
+def pattern_from_cells(cells):
+    """First three vertices of every face, narrowed to float (what ConstructFacePlane reads)."""
+    fvo = cells["face_vert_off"]
+    v = cells["verts"].astype(np.float32)
+    nf = fvo.shape[0] - 1
+    v012 = np.stack([v[fvo[:-1] + k] for k in range(3)], 1).reshape(nf, 9)
+    return cells["cell_face_off"], np.ascontiguousarray(v012)

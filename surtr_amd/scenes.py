@@ -1,0 +1,85 @@
+"""The BASELINE.json configurations as synthetic scenes (inputs of one fracture event).
+
+Everything here is product-side harness code: meshes from meshgen, neighbour
+rings and Voronoi cells through the C ABI host helpers, seeds restated from
+Surtr::GenerateVoronoi / GenerateFracturePattern (Src/Surtr.cpp:1984-2001,
+2072-2096).  Nothing here imports the oracle.
+"""
+import numpy as np
+
+from . import engine, meshgen
+
+SEED = 46354  # FractureArgs::Seed, Inc/Surtr.h:89-110
+
+
+def _canonical(raw):
+    """std::generate_canonical<double,53> over mt19937 (two 32-bit draws per value, libstdc++)."""
+    lo = raw[0::2].astype(np.float64)
+    hi = raw[1::2].astype(np.float64)
+    r = (lo + hi * 4294967296.0) / 18446744073709551616.0
+    return np.minimum(r, np.nextafter(1.0, 0.0))
+
+
+def _mt(seed):
+    bg = np.random.MT19937()
+    bg._legacy_seeding(seed)      # init_genrand(seed) == std::mt19937(seed)
+    return bg
+
+
+def uniform_seeds(n, seed=SEED):
+    """Surtr::GenerateVoronoi(int): uniform(-0.5,0.5)^3 in x,y,z draw order, narrowed to float."""
+    raw = _mt(seed).random_raw(6 * n)
+    r = _canonical(raw)
+    v = r * 1.0 + (-0.5)
+    return v.reshape(n, 3).astype(np.float32).astype(np.float64)
+
+
+def pattern_seeds(n, mean, seed=SEED):
+    """Surtr::GenerateFracturePattern: exponential length (clamped) x normalised uniform(-1,1)^3 direction."""
+    raw = _mt(seed).random_raw(8 * n)
+    r = _canonical(raw).reshape(n, 4)
+    length = np.maximum(np.minimum(-np.log(1.0 - r[:, 0]) / (1.0 / mean), 0.5), 1e-12)
+    d = (r[:, 1:4] * 2.0 + (-1.0)).astype(np.float32)
+    t = d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]
+    ln = np.sqrt((t + d[:, 2] * d[:, 2]).astype(np.float32)).astype(np.float32)
+    d = (d / ln[:, None]).astype(np.float32)
+    return (d * length.astype(np.float32)[:, None]).astype(np.float32).astype(np.float64)
+
+
+def box_solid(extent, center, factor=2.0):
+    """Poly::GetBB scaled by the AABB extent and by 2, translated to the AABB centre
+    (PrepareFracture steps 5, Src/Surtr.cpp:1779-1782).  The k-DOP clip of step 6 is not applied
+    (ACH construction is row f2 of SURVEY.md section 8 and not built yet)."""
+    p = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5],
+                  [-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]], np.float32)
+    nb = np.array([[1, 4, 3], [5, 0, 2], [3, 6, 1], [7, 2, 0], [5, 7, 0], [1, 6, 4], [5, 2, 7], [4, 6, 3]], np.int32)
+    pos = (p * np.asarray(extent, np.float32)) * np.float32(factor) + np.asarray(center, np.float32)
+    return {"pos": pos.astype(np.float32), "off": np.arange(0, 25, 3, dtype=np.uint32), "nbr": nb.reshape(-1)}
+
+
+def make_scene(verts, tris, n_cells, seeds=None):
+    mesh = engine.neighbors_from_mesh(verts, tris)
+    lo, hi = verts.min(0), verts.max(0)
+    extent = (hi - lo).astype(np.float32)
+    center = ((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32)
+    if seeds is None:
+        seeds = uniform_seeds(n_cells)
+    cells = engine.voronoi_cells(seeds)
+    face_off, v012 = engine.pattern_from_cells(cells)
+    return {"mesh": mesh, "convex": box_solid(extent, center), "tris": tris, "seeds": seeds, "cells": cells,
+            "face_off": face_off, "v012": v012, "scale": extent, "translate": center, "n_cells": n_cells}
+
+
+def cube_scene(n_cells=8):
+    v, t = meshgen.cube()
+    return make_scene(v, t, n_cells)
+
+
+def blob_scene(n_cells=64):
+    v, t = meshgen.blob(scale=70.0)
+    return make_scene(v, t, n_cells)
+
+
+def torus_scene(n_cells=4096):
+    v, t = meshgen.bumpy_torus()
+    return make_scene(v, t, n_cells)
