@@ -43,6 +43,10 @@ def run(sc, tag, flags, cells=None):
           "idx", c.n_idx, ref["idx"].shape[0], "status", c.status, "gpu ms first/second %.2f %.2f" % ((t1-t0)*1e3, (t2-t1)*1e3), "cpu s %.3f" % ref["seconds"])
     ok = compare(got, ref, tag)
     print(tag, "PARITY", "OK" if ok else "FAIL")
+    if not ok:
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed("gpurun_out/mismatch_%s.npz" % tag.replace("[", "_").replace("]", "").replace(":", ""),
+                            **{"got_" + k: v for k, v in got.items()}, **{"ref_" + k: v for k, v in ref.items() if k != "seconds"})
     eng.close()
     return ok
 

@@ -391,6 +391,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
     {
         Buf& B = S.b[cur];
         const float4 pl = sh.planes[k];
+        __syncthreads();     // every lane has read the previous plane's flags before they are reset
         if (tid == 0) { sh.flagCut = 0; sh.flagKeep = 0; sh.flagZero = 0; sh.flagBad = 0; }
         __syncthreads();
         // ---- classify (:307-318) ----
@@ -602,6 +603,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             }
         }
 
+        __syncthreads();     // rings and lengths of this plane are final
         // ---- compaction (:464-495) ----
         Buf& D = S.b[cur ^ 1u];
         auto livefn = [&](uint32_t v) -> uint2 {

@@ -240,7 +240,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
                 }
                 if (ch) sh.changed = 1;
                 __syncthreads();
-                if (!sh.changed) break;
+                const bool more = sh.changed != 0;
+                __syncthreads();     // read before lane 0 clears it again
+                if (!more) break;
             }
             auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2(lab[v] == v ? 1u : 0u, 0u); };
             uint32_t ni = 0, dum = 0;
@@ -644,58 +646,72 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         const float* pos = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t* loff = A.loff + fr.mv_off; const uint32_t* llen = A.llen + fr.mv_off;
         const int32_t* nbr = A.nbr + fr.mh_off;           // ring of v starts at loff[v]-mh_off
-        // 1. successor half-edge in the face loop; half-edge id = position in the packed ring array
-        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        // 1. successor half-edge in the face loop; half-edge id = position in the packed ring array.
+        //    A ring that lists a neighbour twice (sliver fragments) breaks the one-loop-per-half-edge
+        //    property: such fragments take the literal, serial ExtractFaces below.
+        if (tid == 0) sh.flagBad = 0;
+        __syncthreads();
         {
-            const uint32_t lo = loff[v] - fr.mh_off, len = llen[v];
-            for (uint32_t s = 0; s < len; ++s)
+            bool dup = false;
+            for (uint32_t v = tid; v < n; v += SURTR_WG)
             {
-                const int32_t b = nbr[lo + s];
-                const uint32_t lb = loff[b] - fr.mh_off, nbq = llen[b];
-                uint32_t q = 0;
-                while (q < nbq && nbr[lb + q] != (int32_t)v) ++q;
-                const uint32_t sq = (q == 0) ? nbq - 1 : q - 1;   // FaceLoop
-                nxA[lo + s] = (int32_t)(lb + sq);
-                keyA[lo + s] = (int32_t)(lo + s);
+                const uint32_t lo = loff[v] - fr.mh_off, len = llen[v];
+                for (uint32_t s = 0; s < len; ++s)
+                {
+                    const int32_t b = nbr[lo + s];
+                    for (uint32_t s2 = 0; s2 < s; ++s2) if (nbr[lo + s2] == b) dup = true;
+                    const uint32_t lb = loff[b] - fr.mh_off, nbq = llen[b];
+                    uint32_t q = 0;
+                    while (q < nbq && nbr[lb + q] != (int32_t)v) ++q;
+                    const uint32_t sq = (q == 0) ? nbq - 1 : q - 1;   // FaceLoop
+                    nxA[lo + s] = (int32_t)(lb + sq);
+                    keyA[lo + s] = (int32_t)(lo + s);
+                }
             }
+            if (dup) sh.flagBad = 1;
         }
         __syncthreads();
-        // 2. minimum half-edge id of every loop by pointer jumping
-        int32_t* kc = keyA; int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
-        for (uint32_t span = 1; span < H; span <<= 1)
-        {
-            for (uint32_t e = tid; e < H; e += SURTR_WG)
-            {
-                const int32_t t = xc[e];
-                const int32_t a = kc[e], b = kc[t];
-                kn[e] = a < b ? a : b;
-                xn[e] = xc[t];
-            }
-            __syncthreads();
-            int32_t* t1 = kc; kc = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
-        }
-        // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order)
-        auto ownfn = [&](uint32_t e) -> uint2 {
-            if (kc[e] != (int32_t)e) return make_uint2(0u, 0u);
-            // loop length by walking
-            uint32_t len = 0;
-            // decode (vertex, slot) of e: binary search over loff
-            uint32_t lo_v = 0, hi_v = n;
-            while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
-            int32_t start = (int32_t)lo_v, prev = start, curv = nbr[e];
-            len = 1;
-            while (curv != start && len <= H)
-            {
-                const uint32_t lc = loff[curv] - fr.mh_off;
-                const int32_t nx = face_next(nbr + lc, llen[curv], prev);
-                prev = curv; curv = nx; ++len;
-            }
-            return make_uint2(1u, len);
-        };
+        const bool irregular = sh.flagBad != 0;
         uint32_t nfaces = 0, lensum = 0;
-        scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
-        if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
+        int32_t* faceLo = nxB; int32_t* faceLen = keyB;
+        if (!irregular)
         {
+            // 2. minimum half-edge id of every loop by pointer jumping
+            int32_t* kc = keyA; int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
+            for (uint32_t span = 1; span < H; span <<= 1)
+            {
+                for (uint32_t e = tid; e < H; e += SURTR_WG)
+                {
+                    const int32_t t = xc[e];
+                    const int32_t a = kc[e], b = kc[t];
+                    kn[e] = a < b ? a : b;
+                    xn[e] = xc[t];
+                }
+                __syncthreads();
+                int32_t* t1 = kc; kc = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
+            }
+            faceLo = xn; faceLen = kn;
+            // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order, Src/Poly.cpp:94-122)
+            auto vertex_of = [&](uint32_t e) -> uint32_t {
+                uint32_t lo_v = 0, hi_v = n;
+                while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
+                return lo_v;
+            };
+            auto ownfn = [&](uint32_t e) -> uint2 {
+                if (kc[e] != (int32_t)e) return make_uint2(0u, 0u);
+                const int32_t start = (int32_t)vertex_of(e);
+                int32_t prev = start, curv = nbr[e];
+                uint32_t len = 1;
+                while (curv != start && len <= H)
+                {
+                    const uint32_t lc = loff[curv] - fr.mh_off;
+                    const int32_t nx = face_next(nbr + lc, llen[curv], prev);
+                    prev = curv; curv = nx; ++len;
+                }
+                return make_uint2(1u, len);
+            };
+            scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
+            if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
             const uint32_t nb = (H + SURTR_LANES - 1u) >> SURTR_LSH;
             for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
             {
@@ -706,10 +722,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 if (e < H && c.x)
                 {
                     const uint32_t fi = blk[b].x + ex.x, lo = blk[b].y + ex.y;
-                    uint32_t lo_v = 0, hi_v = n;
-                    while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
                     int32_t* loop = loopbuf + lo;
-                    int32_t start = (int32_t)lo_v, prev = start, curv = nbr[e];
+                    const int32_t start = (int32_t)vertex_of(e);
+                    int32_t prev = start, curv = nbr[e];
                     uint32_t len = 1; loop[0] = start;
                     while (curv != start && len < c.y)
                     {
@@ -718,13 +733,64 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                         const int32_t nx = face_next(nbr + lc, llen[curv], prev);
                         prev = curv; curv = nx;
                     }
-                    // 4. triangulate; room for 3*(len-2) indices at 3*(lo - 2*fi)
-                    uint32_t* out = tri + 3u * (lo - 2u * fi);
-                    fcnt[fi] = ear_clip_face(pos, loop, (int)len, eartmp + 3 * (size_t)lo, out);
-                    // remember where this face's triangles start
-                    xn[fi] = (int32_t)(3u * (lo - 2u * fi));
+                    faceLo[fi] = (int32_t)lo; faceLen[fi] = (int32_t)len;
                 }
             }
+        }
+        else
+        {
+            // literal ExtractFaces (Src/Poly.cpp:89-126) on one lane; the visited set is keyed by the
+            // (vertex, neighbour) pair = the first slot holding that neighbour
+            if (tid == 0)
+            {
+                int32_t* visited = keyA;
+                for (uint32_t e = 0; e < H; ++e) visited[e] = 0;
+                auto slot_of = [&](int32_t a, int32_t b) -> uint32_t {
+                    const uint32_t la = loff[a] - fr.mh_off, na = llen[a];
+                    uint32_t q = 0;
+                    while (q < na && nbr[la + q] != b) ++q;
+                    return la + (q < na ? q : 0u);
+                };
+                uint32_t nfc = 0, lo = 0; bool bad = false;
+                for (uint32_t i = 0; i < n && !bad; ++i)
+                {
+                    const uint32_t li = loff[i] - fr.mh_off, ni = llen[i];
+                    for (uint32_t s = 0; s < ni && !bad; ++s)
+                    {
+                        const int32_t adj = nbr[li + s];
+                        if (visited[slot_of((int32_t)i, adj)]) continue;
+                        if (lo + 1 > HF || nfc >= HF) { bad = true; break; }
+                        uint32_t len = 1; loopbuf[lo] = (int32_t)i;
+                        int32_t prev = (int32_t)i, curv = adj;
+                        while (curv != (int32_t)i)
+                        {
+                            visited[slot_of(prev, curv)] = 1;
+                            if (lo + len >= HF || len > H) { bad = true; break; }
+                            loopbuf[lo + len++] = curv;
+                            const uint32_t lc = loff[curv] - fr.mh_off;
+                            const int32_t nx = face_next(nbr + lc, llen[curv], prev);
+                            prev = curv; curv = nx;
+                        }
+                        if (bad) break;
+                        visited[slot_of(prev, curv)] = 1;
+                        faceLo[nfc] = (int32_t)lo; faceLen[nfc] = (int32_t)len; ++nfc; lo += len;
+                    }
+                }
+                sh.misc[0] = nfc; sh.misc[1] = lo; sh.misc[2] = bad ? 1u : 0u;
+            }
+            __syncthreads();
+            nfaces = sh.misc[0]; lensum = sh.misc[1];
+            const bool bad = sh.misc[2] != 0;
+            __syncthreads();
+            if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
+        }
+        __syncthreads();
+        // 4. triangulate every face on its own lane; room for 3*len indices at 3*lo
+        for (uint32_t fi = tid; fi < nfaces; fi += SURTR_WG)
+        {
+            const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
+            uint32_t* out = tri + 3u * (size_t)lo;
+            fcnt[fi] = (len >= 3u) ? ear_clip_face(pos, loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out) : 0u;
         }
         __syncthreads();
         // 5. compact the triangle lists of the faces, in face order, into the index arena
@@ -745,7 +811,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 const uint2 ex = wave_excl2(c);
                 if (fi < nfaces && c.x)
                 {
-                    const uint32_t* src = tri + (uint32_t)xn[fi];
+                    const uint32_t* src = tri + 3u * (size_t)(uint32_t)faceLo[fi];
                     uint32_t* dst = A.idx + ioff + blk[b].x + ex.x;
                     for (uint32_t q = 0; q < c.x; ++q) dst[q] = src[q];
                 }
