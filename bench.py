@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- fragments/sec + ms/fracture-event on BASELINE.json's configs[3]:
+100k-triangle synthetic mesh (bumpy torus, 50 000 v / 100 000 tri) x 4096 Voronoi cells.
+
+A "step" is one fracture event on device-resident inputs: cell placement (A3), clip of Convex and
+Mesh against every cell + island split (A7, A8, A11), refit (A12), face extraction + ear clipping
+(A9, A10), pack of the fragment blob, and -- for N > 1 -- one all-gather of the blobs over RCCL.
+Cells are sharded in contiguous blocks over the ranks (strong scaling: total work fixed).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (k_clip_pairs), timed live with
+HIP events on the work stream; `cpu_baseline` is the CPU oracle ("port") run on the host cores on
+rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(sc, counts, n_faces):
+    """compulsory traffic of one event, from the run's actual counts."""
+    V = sc["mesh"]["pos"].shape[0]
+    H = sc["mesh"]["nbr"].shape[0]
+    cV = sc["convex"]["pos"].shape[0]
+    cH = sc["convex"]["nbr"].shape[0]
+    C = sc["n_cells"]
+    b_in = (12 * V + 4 * (V + 1) + 4 * H) + (12 * cV + 4 * (cV + 1) + 4 * cH) + 16 * n_faces + 4 * (C + 1)
+    nf = counts.n_frag
+    solids = (12 * counts.mesh_verts + 4 * (counts.mesh_verts + nf) + 4 * counts.mesh_nbrs) + \
+             (12 * counts.conv_verts + 4 * (counts.conv_verts + nf) + 4 * counts.conv_nbrs)
+    render = 36 * counts.mesh_verts + 4 * counts.n_idx
+    ids = 12 * nf
+    return {"in": b_in, "solids": solids, "render": render, "ids": ids, "event": b_in + solids + render + ids,
+            "clip_kernel": b_in + solids + ids}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    if not os.path.exists(os.path.join(ROOT, "surtr_amd", "libsurtr_hip.so")):
+        import __graft_entry__
+        if rank == 0:
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
+    from surtr_amd import engine, scenes, multigpu
+
+    sc = scenes.torus_scene(args.cells)
+    eng = engine.Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    cb, ce = engine.cell_block(rank, world, sc["n_cells"])
+    flags = engine.EVT_REFIT | engine.EVT_RENDER
+
+    # sizing pass: blob capacity for the timed loop (sizes are identical every step: same inputs)
+    eng.place_cells(sc["scale"], sc["translate"])
+    counts = eng.fracture_event(cb, ce, flags=flags)
+    my_bytes = engine.blob_bytes(counts)
+    cap_t = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+    cap = (int(cap_t.item()) + 4095) // 4096 * 4096
+    blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if world > 1 else blob
+
+    def step():
+        eng.place_cells(sc["scale"], sc["translate"])
+        eng.fracture_event_async(cb, ce, flags=flags)
+        eng.pack_dev(blob.data_ptr(), cap)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, blob)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+
+    # fragment totals over ranks (from the gathered blob headers)
+    host = gathered.cpu().numpy()
+    total_frag = 0
+    parts = []
+    for r in range(world):
+        c, fr = engine.unpack_blob(host[r * cap:(r + 1) * cap])
+        assert c.status == 0, "device status %d on rank %d" % (c.status, r)
+        total_frag += c.n_frag
+        parts.append((c, fr))
+
+    # dominant-kernel timing with HIP events on the work stream (separate short loop, same work)
+    eng.set_profiling(True)
+    clip_ms = []
+    all_ms = {}
+    for _ in range(max(3, min(args.steps, 10))):
+        eng.place_cells(sc["scale"], sc["translate"])
+        eng.fracture_event_async(cb, ce, flags=flags)
+        eng.pack_dev(blob.data_ptr(), cap)
+        t = eng.kernel_times()
+        clip_ms.append(t["clip_pairs"])
+        for k, v in t.items():
+            all_ms.setdefault(k, []).append(v)
+    eng.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_frag / (dt / args.steps)
+        counts0 = parts[0][0]
+        n_faces_rank = int(sc["face_off"][ce] - sc["face_off"][cb])
+        sc_rank = dict(sc, n_cells=ce - cb)
+        ab = algorithmic_bytes(sc_rank, counts0, n_faces_rank)
+        clip_avg_ms = float(np.mean(clip_ms))
+        achieved = ab["clip_kernel"] / (clip_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tj):
+            try:
+                traffic = json.load(open(tj)).get("k_clip_pairs_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fragments/sec", "value": value, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "bumpy torus 50000 v / 100000 tri x %d Voronoi cells (BASELINE configs[3]), "
+                                   "1 piece (mesh + 2x bounding-box convex), refit + triangulation on" % sc["n_cells"],
+                       "cells": sc["n_cells"], "fragments": total_frag, "parallelism": "cells sharded x%d" % world},
+            "ms_per_fracture_event": ms_per_step,
+            "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
+            "roofline": {"kernel": "k_clip_pairs", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": ab["clip_kernel"], "event_algorithmic_bytes": ab["event"],
+                         "avg_launch_ms": clip_avg_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle
+            threads = 16          # the reference's pool: dp::thread_pool g_threadPool(16), Src/Surtr.cpp:28
+            planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+            ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=True, render=True, threads=threads)
+            nref = int(ref["frag_ids"].shape[0])
+            out["cpu_baseline"] = {"value": nref / ref["seconds"], "unit": "fragments/s", "cores": threads, "kind": "port",
+                                   "sample": "whole event, %d cells, one task per cell on %d worker threads, %.2f s wall "
+                                             "(host has %d logical cores)" % (sc["n_cells"], threads, ref["seconds"], os.cpu_count()),
+                                   "ms_per_event": ref["seconds"] * 1e3}
+            out["parity_check"] = {"fragments_gpu": total_frag, "fragments_cpu": nref,
+                                   "mesh_nbr_equal": bool(np.array_equal(parts[0][1]["mesh_nbr"], ref["mesh_nbr"])),
+                                   "idx_equal": bool(np.array_equal(parts[0][1]["idx"], ref["idx"]))}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

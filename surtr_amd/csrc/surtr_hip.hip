@@ -1019,7 +1019,21 @@ struct surtr_ctx
     bool have_event = false; uint32_t last_flags = 0;
     // staging for downloads
     void* d_blob = nullptr; size_t blob_cap = 0;
+    // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
+    bool profiling = false;
+#ifndef SURTR_EMUL
+    hipEvent_t ev[16] = {};
+#endif
+    bool ev_valid[8] = {};
 };
+
+#ifndef SURTR_EMUL
+#define PROF_BEGIN(i) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], st); } } while (0)
+#define PROF_END(i) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], st); ctx->ev_valid[i] = true; } } while (0)
+#else
+#define PROF_BEGIN(i) do { } while (0)
+#define PROF_END(i) do { } while (0)
+#endif
 
 #define HIPCHK(call)                                                                              \
     do {                                                                                          \
@@ -1347,17 +1361,32 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
     }
     Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri,
              ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->n_pieces};
+    for (int i = 0; i < 8; ++i) ctx->ev_valid[i] = false;
+    PROF_BEGIN(0);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            d_out, ctx->pool, ctx->arena, ctx->d_pairs);
+    PROF_END(0);
+    PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
                        ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts);
+    PROF_END(1);
     if (flags & SURTR_EVT_REFIT)
+    {
+        PROF_BEGIN(2);
         hipLaunchKernelGGL(k_refit, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool, ctx->arena);
+        PROF_END(2);
+    }
     if (flags & SURTR_EVT_RENDER)
+    {
+        PROF_BEGIN(3);
         hipLaunchKernelGGL(k_faces, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
                            ctx->blk_per_wg, ctx->arena);
+        PROF_END(3);
+    }
+    PROF_BEGIN(4);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    PROF_END(4);
     HIPCHK(hipGetLastError());
     ctx->have_event = true; ctx->last_flags = flags;
     return SURTR_OK;
@@ -1398,9 +1427,37 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
     (void)hipSetDevice(ctx->device);
     // capacity is checked on the device against the counts it holds; the host check uses the last fetched counts if any
     const uint32_t grid = std::max(1u, std::min(ctx->cap_frags, 2048u));
+    hipStream_t st = ctx->stream;
+    PROF_BEGIN(5);
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(SURTR_WG), 0, ctx->stream, ctx->d_frags, ctx->d_counts, ctx->arena, (char*)dev_blob,
                        capacity, (ctx->last_flags & SURTR_EVT_RENDER) ? 1u : 0u);
+    PROF_END(5);
     HIPCHK(hipGetLastError());
+    return SURTR_OK;
+}
+
+int surtr_set_profiling(surtr_ctx* ctx, int on)
+{
+    if (!ctx) return SURTR_E_INVALID;
+#ifndef SURTR_EMUL
+    (void)hipSetDevice(ctx->device);
+    if (on && !ctx->ev[0])
+        for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreate(&ctx->ev[i]));
+#endif
+    ctx->profiling = on != 0;
+    return SURTR_OK;
+}
+
+int surtr_kernel_times(surtr_ctx* ctx, float ms[8])
+{
+    if (!ctx || !ms) return SURTR_E_INVALID;
+    for (int i = 0; i < 8; ++i) ms[i] = -1.f;
+#ifndef SURTR_EMUL
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 8; ++i)
+        if (ctx->ev_valid[i]) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ms[i] = t; }
+#endif
     return SURTR_OK;
 }
 

@@ -127,6 +127,15 @@ class Engine:
     def set_arena(self, verts, nbrs, idx):
         self._ck(lib().surtr_set_arena(self._h, ctypes.c_uint64(verts), ctypes.c_uint64(nbrs), ctypes.c_uint64(idx)))
 
+    def set_profiling(self, on=True):
+        self._ck(lib().surtr_set_profiling(self._h, ctypes.c_int(int(on))))
+
+    def kernel_times(self):
+        ms = (ctypes.c_float * 8)()
+        self._ck(lib().surtr_kernel_times(self._h, ms))
+        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack")
+        return {n: float(ms[i]) for i, n in enumerate(names)}
+
     def upload_pieces(self, meshes, convexes):
         assert len(meshes) == len(convexes)
         m = pack_solids(meshes)
@@ -277,3 +286,36 @@ def pattern_from_cells(cells):
     nf = fvo.shape[0] - 1
     v012 = np.stack([v[fvo[:-1] + k] for k in range(3)], 1).reshape(nf, 9)
     return cells["cell_face_off"], np.ascontiguousarray(v012)
+
+
+def merge_fragments(parts):
+    """Concatenates the fragment sets of consecutive cell blocks (one per rank, in rank order) into one
+    set with rebased offsets: the cell-major order of Surtr::ApplyFracture (Src/Surtr.cpp:2133-2146)."""
+    out = {}
+    out["frag_ids"] = np.concatenate([p["frag_ids"].reshape(-1, 3) for p in parts])
+    for pre in ("mesh", "conv"):
+        vo, no, vbase, nbase = [np.zeros(1, np.uint32)], [np.zeros(1, np.uint32)], 0, 0
+        for p in parts:
+            pvo, pno = p[pre + "_vert_off"].astype(np.int64), p[pre + "_nbr_off"].astype(np.int64)
+            vo.append((pvo[1:] + vbase).astype(np.uint32))
+            no.append((pno[1:] + nbase).astype(np.uint32))
+            vbase += int(pvo[-1])
+            nbase += int(pno[-1])
+        out[pre + "_vert_off"] = np.concatenate(vo)
+        out[pre + "_nbr_off"] = np.concatenate(no)
+        out[pre + "_pos"] = np.concatenate([p[pre + "_pos"].reshape(-1, 3) for p in parts])
+        out[pre + "_nbr"] = np.concatenate([p[pre + "_nbr"] for p in parts])
+    io, ibase = [np.zeros(1, np.uint32)], 0
+    for p in parts:
+        pio = p["idx_off"].astype(np.int64)
+        io.append((pio[1:] + ibase).astype(np.uint32))
+        ibase += int(pio[-1])
+    out["idx_off"] = np.concatenate(io)
+    out["idx"] = np.concatenate([p["idx"] for p in parts])
+    out["vnc"] = np.concatenate([p["vnc"].reshape(-1, 9) for p in parts])
+    return out
+
+
+def cell_block(rank, world, n_cells):
+    """Contiguous cell block of a rank: [floor(r*C/G), floor((r+1)*C/G))."""
+    return (rank * n_cells) // world, ((rank + 1) * n_cells) // world

@@ -1,0 +1,147 @@
+"""CPU tier: the product kernels compiled as a single-lane emulation (tests/emul) against the oracle.
+This checks kernel *logic* (ordering rules, in-plane fallback, band reduction); races need the GPU tier."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from helpers import assert_event_equal, fragment, run_event
+from surtr_amd import scenes
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_cube_8_cells(emul_engine, oracle, flags):
+    c, got, ref = run_event(emul_engine, oracle, scenes.cube_scene(8), flags)
+    assert c.n_frag == 8
+    assert_event_equal(got, ref, render=bool(flags & 2))
+
+
+def test_blob_64_cells(emul_engine, oracle):
+    c, got, ref = run_event(emul_engine, oracle, scenes.blob_scene(64), 3)
+    assert c.n_frag == ref["frag_ids"].shape[0] > 40
+    assert_event_equal(got, ref)
+    assert np.array_equal(got["mesh_pos"], ref["mesh_pos"])       # same float program => bit-exact here
+
+
+def test_blob_1024_cells_sample(emul_engine, oracle):
+    c, got, ref = run_event(emul_engine, oracle, scenes.blob_scene(1024), 3, cells=160)
+    assert_event_equal(got, ref)
+
+
+def test_torus_sample(emul_engine, oracle):
+    sc = scenes.make_scene(*__import__("surtr_amd.meshgen", fromlist=["x"]).bumpy_torus(100, 60), 256)
+    c, got, ref = run_event(emul_engine, oracle, sc, 3, cells=48)
+    assert c.n_frag > 0
+    assert_event_equal(got, ref)
+
+
+def test_islands_are_split_like_the_reference(emul_engine, oracle):
+    # two disjoint cubes in one piece: every cell that meets both yields two islands
+    from surtr_amd import engine, meshgen
+    v, t = meshgen.cube(1.0)
+    v2 = np.concatenate([v, v + np.float32([5, 0, 0])])
+    t2 = np.concatenate([t, t + 8])
+    sc = scenes.make_scene(v2, t2, 6)
+    c, got, ref = run_event(emul_engine, oracle, sc, 3)
+    assert got["frag_ids"][:, 2].max() >= 1
+    assert_event_equal(got, ref)
+
+
+def test_outside_mask_skips_pieces(emul_engine, oracle):
+    sc = scenes.cube_scene(8)
+    eng = emul_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"], sc["mesh"]], [sc["convex"], sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    c = eng.fracture_event(0, 8, outside=[1, 0], flags=3)
+    got = eng.download()
+    eng.close()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]] * 2, [sc["convex"]] * 2, sc["face_off"], planes, outside=[1, 0])
+    assert np.all(got["frag_ids"][:, 1] == 1)
+    assert_event_equal(got, ref)
+
+
+def test_clip_polyhedron_kats(emul_engine, oracle):
+    eng = emul_engine.Engine(0)
+    box = oracle.unit_box()
+    for planes in ([[1, 1, 1, 0]], [[1, 0, 0, -0.5]], [[1, 1, 0, 0]], [[1, 0, 0, 0], [0, 1, 0, 0], [1, 1, 1, -0.2]],
+                   [[0, 0, 0, 0]], [[0, 0, 0, 1]], [[1, 0, 0, 0.25], [-1, 0, 0, 0.25]]):
+        pl = np.array(planes, np.float32)
+        a = eng.clip_polyhedron(box, pl)
+        b = oracle.clip(box, pl)
+        assert a["pos"].shape == b["pos"].shape, planes
+        assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]), planes
+        assert np.array_equal(a["pos"], b["pos"]), planes
+    assert eng.clip_polyhedron(box, np.array([[1, 0, 0, 1.5]], np.float32))["pos"].shape[0] == 0
+    eng.close()
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(st.lists(st.tuples(st.floats(-1, 1), st.floats(-1, 1), st.floats(-1, 1), st.floats(-0.6, 0.3)), min_size=1, max_size=10),
+       st.booleans())
+def test_random_planes_on_box_and_blob(emul_engine, oracle, planes, use_blob):
+    pl = np.array(planes, np.float32)
+    pl = pl[np.abs(pl[:, :3]).sum(1) > 1e-3]
+    if pl.shape[0] == 0:
+        return
+    solid = scenes.blob_scene(8)["mesh"] if use_blob else oracle.unit_box()
+    if use_blob:
+        solid = dict(solid, pos=solid["pos"] / 70.0)
+    eng = emul_engine.Engine(0)
+    a = eng.clip_polyhedron(solid, pl)
+    eng.close()
+    b = oracle.clip(solid, pl)
+    assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"])
+    assert np.array_equal(a["pos"], b["pos"])
+
+
+def test_axis_aligned_grid_of_cells_hits_in_plane_path(emul_engine, oracle):
+    # cube mesh cut by cells whose walls pass exactly through mesh vertices and edges (comp == 0 everywhere)
+    from surtr_amd import meshgen, engine
+    v, t = meshgen.cube(1.0)
+    mesh = engine.neighbors_from_mesh(v, t)
+    planes, off = [], [0]
+    for ix in (-1, 0):
+        for iy in (-1, 0):
+            x0, x1, y0, y1 = ix, ix + 1, iy, iy + 1
+            planes += [[-1, 0, 0, x0], [1, 0, 0, -x1], [0, -1, 0, y0], [0, 1, 0, -y1], [0, 0, -1, -1], [0, 0, 1, -1]]
+            off.append(len(planes))
+    planes = np.array(planes, np.float32)
+    eng = emul_engine.Engine(0)
+    eng.upload_pieces([mesh], [scenes.box_solid([2, 2, 2], [0, 0, 0])])
+    eng.upload_planes(off, planes)
+    c = eng.fracture_event(0, 4, flags=3)
+    got = eng.download()
+    eng.close()
+    ref = oracle.event([mesh], [scenes.box_solid([2, 2, 2], [0, 0, 0])], off, planes)
+    assert c.n_frag == 4
+    assert_event_equal(got, ref)
+    vols = [oracle.moments(fragment(got, k))[0] for k in range(4)]
+    assert np.allclose(vols, 2.0, atol=1e-5)
+
+
+def test_upload_rejects_bad_topology(emul_engine):
+    sc = scenes.cube_scene(8)
+    bad = dict(sc["mesh"], nbr=sc["mesh"]["nbr"].copy())
+    bad["nbr"][0] = (bad["nbr"][0] + 3) % 8
+    eng = emul_engine.Engine(0)
+    with pytest.raises(emul_engine.SurtrError) as e:
+        eng.upload_pieces([bad], [sc["convex"]])
+    assert e.value.code == emul_engine.E_TOPOLOGY
+    with pytest.raises(emul_engine.SurtrError) as e:
+        eng.fracture_event(0, 1)
+    assert e.value.code == emul_engine.E_STATE
+    eng.close()
+
+
+def test_capacity_error_is_reported(emul_engine):
+    sc = scenes.blob_scene(64)
+    eng = emul_engine.Engine(0)
+    eng.set_arena(64, 256, 256)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    with pytest.raises(emul_engine.SurtrError) as e:
+        eng.fracture_event(0, 64)
+    assert e.value.code == emul_engine.E_CAPACITY
+    eng.close()

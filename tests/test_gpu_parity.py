@@ -1,0 +1,171 @@
+"""GPU tier (-m gpu): the HIP path, called through the C ABI, against the oracle on the same seeded inputs,
+against the committed golden fixtures, and -- at BASELINE.json's full size -- through size-independent
+properties.  Bit-exact for indices/topology; coordinates within 1e-5 relative (north_star)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import RTOL, assert_event_equal, fragment, run_event
+from surtr_amd import scenes
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOPO = ("frag_ids", "mesh_vert_off", "mesh_nbr_off", "mesh_nbr", "conv_vert_off", "conv_nbr_off", "conv_nbr", "idx_off", "idx")
+
+
+@pytest.fixture(scope="module")
+def torus_run():
+    from surtr_amd import engine
+    from oracle import oracle
+    engine._use_library_for_tests(None)
+    sc = scenes.torus_scene(4096)
+    c, got, ref = run_event(engine, oracle, sc, 3, threads=16)
+    return sc, c, got, ref
+
+
+@pytest.mark.parametrize("flags", [0, 1, 2, 3])
+def test_cube_8_cells(gpu_engine, oracle, flags):
+    c, got, ref = run_event(gpu_engine, oracle, scenes.cube_scene(8), flags)
+    assert c.n_frag == 8 and c.status == 0
+    assert_event_equal(got, ref, render=bool(flags & 2))
+
+
+def test_cube_golden_fixture(gpu_engine):
+    g = np.load(os.path.join(HERE, "cube8.npz"))
+    sc = scenes.cube_scene(8)
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_planes(g["face_off"], g["planes"])
+    eng.fracture_event(0, 8, flags=3)
+    got = eng.download()
+    eng.close()
+    for k in TOPO:
+        assert np.array_equal(got[k], g["out_" + k]), k
+    for k in ("mesh_pos", "conv_pos"):
+        assert np.allclose(got[k], g["out_" + k], rtol=RTOL, atol=1e-6), k
+
+
+def test_place_cells_matches_oracle(gpu_engine, oracle):
+    # cell placement kernel (A3): compare through a clip that is sensitive to the planes
+    sc = scenes.blob_scene(64)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    a = gpu_engine.Engine(0)
+    a.upload_pieces([sc["mesh"]], [sc["convex"]])
+    a.upload_pattern(sc["face_off"], sc["v012"])
+    a.place_cells(sc["scale"], sc["translate"])
+    a.fracture_event(0, 64, flags=0)
+    x = a.download()
+    a.upload_planes(sc["face_off"], planes)
+    a.fracture_event(0, 64, flags=0)
+    y = a.download()
+    a.close()
+    for k in ("mesh_pos", "mesh_nbr", "conv_pos", "conv_nbr"):
+        assert np.array_equal(x[k], y[k]), k
+
+
+@pytest.mark.parametrize("name,n", [("blob64", 64), ("blob1024", 1024)])
+def test_blob_configs(gpu_engine, oracle, name, n):
+    c, got, ref = run_event(gpu_engine, oracle, scenes.blob_scene(n), 3, threads=8)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    want = json.load(open(os.path.join(HERE, "digests.json")))[name]
+    assert c.n_frag == want["n_frag"] and c.mesh_verts == want["mesh_verts"] and c.n_idx == want["n_idx"]
+    for k in TOPO:
+        assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == want[k], k
+    assert abs(float(got["mesh_pos"].astype(np.float64).sum()) - want["mesh_pos_sum"]) <= 1e-5 * abs(want["mesh_pos_sum"]) + 1e-3
+
+
+def test_torus_4096_full_event_vs_oracle_and_digest(torus_run):
+    sc, c, got, ref = torus_run
+    assert c.status == 0 and c.n_pairs == 4096
+    assert_event_equal(got, ref)
+    want = json.load(open(os.path.join(HERE, "digests.json")))["torus4096"]
+    assert c.n_frag == want["n_frag"] and c.mesh_verts == want["mesh_verts"] and c.n_idx == want["n_idx"]
+    for k in TOPO:
+        assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == want[k], k
+
+
+def test_torus_4096_properties(torus_run, oracle):
+    sc, c, got, ref = torus_run
+    nf = c.n_frag
+    # (1) fragments partition the solid: sum of volumes = volume of the mesh
+    vols = np.array([oracle.moments(fragment(got, k))[0] for k in range(nf)])
+    whole = oracle.moments(sc["mesh"])[0]
+    # float32 clipping of 4096 cells: the oracle (bit-identical output) shows the same 2e-5 drift
+    assert abs(vols.sum() - whole) / whole < 1e-4
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    mvo, mno = got["mesh_vert_off"].astype(np.int64), got["mesh_nbr_off"].astype(np.int64)
+    ioff = got["idx_off"].astype(np.int64)
+    for k in range(0, nf, 7):
+        fr = fragment(got, k)
+        nv = fr["pos"].shape[0]
+        off = fr["off"].astype(np.int64)
+        # (2) neighbour links are symmetric (Src/Poly.cpp:253-260)
+        src = np.repeat(np.arange(nv), np.diff(off))
+        pairs = set(zip(src.tolist(), fr["nbr"].tolist()))
+        assert all((b, a) in pairs for a, b in pairs)
+        # (3) every vertex satisfies every plane of its cell
+        cell = int(got["frag_ids"][k, 0])
+        pl = planes[sc["face_off"][cell]:sc["face_off"][cell + 1]].astype(np.float64)
+        s = fr["pos"].astype(np.float64) @ pl[:, :3].T + pl[:, 3]
+        assert s.max() < 1e-4
+        # (4) index buffers reference only the fragment's own vertices, whole triangles
+        idx = got["idx"][ioff[k]:ioff[k + 1]]
+        assert idx.size % 3 == 0 and (idx.size == 0 or idx.max() < nv)
+        # (5) every half-edge lies in exactly one face loop; triangle count = sum(len-2) unless a face was dropped
+        fo, fi = oracle.extract_faces(fr)
+        assert fo[-1] == fr["nbr"].shape[0]
+        assert idx.size <= 3 * int((np.diff(fo.astype(np.int64)) - 2).sum())
+    # (6) cell-major order, islands numbered from 0
+    ids = got["frag_ids"]
+    key = ids[:, 0].astype(np.int64) * 10 ** 6 + ids[:, 1] * 10 ** 3 + ids[:, 2]
+    assert np.all(np.diff(key) > 0)
+
+
+def test_clip_polyhedron_operator(gpu_engine, oracle):
+    eng = gpu_engine.Engine(0)
+    box = oracle.unit_box()
+    for planes in ([[1, 1, 1, 0]], [[1, 0, 0, -0.5]], [[1, 1, 0, 0]], [[0, 0, 0, 0]], [[1, 0, 0, 0.25], [-1, 0, 0, 0.25]]):
+        pl = np.array(planes, np.float32)
+        a, b = eng.clip_polyhedron(box, pl), oracle.clip(box, pl)
+        assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]), planes
+        assert np.allclose(a["pos"], b["pos"], rtol=RTOL, atol=1e-7), planes
+    sc = scenes.blob_scene(8)
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        n = rng.normal(size=(5, 3)).astype(np.float32)
+        pl = np.concatenate([n, rng.uniform(-40, 5, size=(5, 1)).astype(np.float32)], 1)
+        a, b = eng.clip_polyhedron(sc["mesh"], pl), oracle.clip(sc["mesh"], pl)
+        assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"])
+        assert np.allclose(a["pos"], b["pos"], rtol=RTOL, atol=1e-5)
+    eng.close()
+
+
+def test_in_plane_cells_and_islands(gpu_engine, oracle):
+    from surtr_amd import meshgen
+    v, t = meshgen.cube(1.0)
+    v2 = np.concatenate([v, v + np.float32([5, 0, 0])])
+    t2 = np.concatenate([t, t + 8])
+    sc = scenes.make_scene(v2, t2, 6)
+    c, got, ref = run_event(gpu_engine, oracle, sc, 3)
+    assert got["frag_ids"][:, 2].max() >= 1
+    assert_event_equal(got, ref)
+
+
+def test_repeatable(gpu_engine):
+    sc = scenes.blob_scene(64)
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    eng.fracture_event(0, 64)
+    a = eng.download()
+    for _ in range(3):
+        eng.fracture_event(0, 64)
+        b = eng.download()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    eng.close()

@@ -1,0 +1,55 @@
+"""world_size-2 gloo test of the multi-GPU path: cells sharded in contiguous blocks, one all-gather of the
+packed fragment blobs, deterministic concatenation.  Runs on CPU with the emulated kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, emul_path, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from surtr_amd import engine, scenes
+    from surtr_amd.multigpu import allgather_fragments
+    engine._use_library_for_tests(emul_path)
+    sc = scenes.blob_scene(64)
+    eng = engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    b, e = engine.cell_block(rank, world, sc["n_cells"])
+    c = eng.fracture_event(b, e, flags=3)
+    merged = allgather_fragments(eng, c, device="cpu")
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **merged)
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one(tmp_path, emul_lib_path, oracle):
+    from surtr_amd import scenes
+    from helpers import assert_event_equal
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, emul_lib_path, str(tmp_path)), nprocs=2, join=True)
+    sc = scenes.blob_scene(64)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, threads=4)
+    for r in range(2):
+        got = dict(np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)))
+        assert_event_equal(got, ref)
+
+
+def test_cell_blocks_cover_all_cells():
+    from surtr_amd import engine
+    for world in (1, 2, 3, 4, 8):
+        for n in (1, 7, 64, 4096):
+            blocks = [engine.cell_block(r, world, n) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
