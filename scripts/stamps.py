@@ -1,0 +1,26 @@
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from surtr_amd import engine as E, scenes as S
+sc = S.torus_scene(4096)
+lib = os.path.abspath(sys.argv[1])
+E._use_library_for_tests(lib)
+L = E.lib()
+eng = E.Engine(0)
+eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+c = eng.fracture_event(0, 4096, flags=flags)
+buf = (ctypes.c_ulonglong * 32)()
+L.surtr_debug_stamps(buf, 1)
+c = eng.fracture_event(0, 4096, flags=flags)
+L.surtr_debug_stamps(buf, 1)
+names = ["pre: band mask", "pre: block scan", "pre: emit reduced", "pre: hist", "plane: classify", "plane: new verts", "plane: relink", "plane: compaction",
+         "pair setup", "planes->LDS", "(convex clip total)", "park convex", "(mesh clip total)", "islands label", "islands park", "queue"]
+tot = sum(buf[i] for i in (0,1,2,3,4,5,6,7,8,9,11,13,14,15))
+for i, n in enumerate(names):
+    print("%-20s %14d  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
+print("total cycles (lane0, summed over WGs)", tot)
+print("serial planes", buf[19], "nodrop solids", buf[20])
+print("pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[21 + i] for i in range(11)])
+print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[18], 1), buf[17], buf[18]))
+eng.close()

@@ -29,8 +29,10 @@
 #include <hip/hip_runtime.h>
 #define SURTR_LANES 64
 #define SURTR_LSH 6
+#ifndef SURTR_WG
 #define SURTR_WG 256
-#define SURTR_NWAVE 4
+#endif
+#define SURTR_NWAVE (SURTR_WG / 64)
 #endif
 #include <stdint.h>
 #ifdef SURTR_EMUL
@@ -40,8 +42,22 @@
 #define SURTR_DBG(...)
 #endif
 
+// Diagnostic build only (-DSURTR_STAMP): lane 0 accumulates s_memtime deltas per phase into a
+// global table that no product code reads.
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+__device__ unsigned long long g_stamp[32];
+#define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
+#define STAMP(i) do { if (threadIdx.x == 0) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); st_t0 = st_t1; } } while (0)
+#define COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_stamp[i], 1ull); } while (0)
+#else
+#define COUNT(i) do { } while (0)
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#endif
+
 #define SURTR_MAXF 255
 #define SURTR_SENT (-2)
+#define SURTR_LDS_BLOCKS 1024   // pre-pass masks live in LDS for solids up to 64*1024 vertices
 
 namespace surtr {
 
@@ -60,8 +76,7 @@ struct Scratch
     uint32_t* aux0;   // [CV]
     uint32_t* aux1;   // [CV]
     uint32_t* aux2;   // [CV]
-    uint8_t* fc;      // [VMAX] first cutting plane of every original vertex, 0xFF = none
-    int32_t* newid;   // [VMAX] index in the reduced solid, SURTR_SENT = dropped
+    unsigned long long* gmask;   // [VMAX/64] pre-pass band mask when the solid is too big for the LDS copy
     uint2* blk;       // per-64-block (count, weight) of the ordered scans
     uint32_t CV, CH;
 };
@@ -70,12 +85,15 @@ struct Shared
 {
     float4 planes[SURTR_MAXF + 1];
     uint32_t hist[SURTR_MAXF + 1];
+    uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t wsum[2 * SURTR_NWAVE];
     uint32_t flagCut, flagKeep, flagZero, flagBad, flagErr;
     uint32_t hend;
     uint32_t nodrop;
     uint32_t changed;
     uint32_t misc[8];
+    unsigned long long bmask[SURTR_LDS_BLOCKS];   // band bit mask of the pre-pass, one word per 64 vertices
+    uint2 bblk[SURTR_LDS_BLOCKS];                 // (count, ring entries) bases per 64 vertices
 };
 
 // A solid handed to the clipper: positions + (loff, llen) rings with entries local to the solid.
@@ -123,20 +141,10 @@ __device__ __forceinline__ uint2 wave_incl_scan2(uint2 v)
 // Ordered two-level scan over items [0,n): phase 1+2.  fn(i) -> (count, weight).
 // After the call blk[b] holds the exclusive (count, weight) base of 64-block b
 // and (totC, totW) the totals.  Every thread must call it (barriers inside).
-template <class Fn>
-__device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t& totC, uint32_t& totW)
+// Exclusive scan, in place, of the per-64-block (count, weight) array; returns the totals.
+__device__ inline void scan_block_array(uint32_t nb, uint2* blk, Shared& sh, uint32_t& totC, uint32_t& totW)
 {
-    const uint32_t nb = (n + SURTR_LANES - 1u) >> SURTR_LSH;
     const uint32_t l = lane_id(), w = wave_id();
-    for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
-    {
-        const uint32_t i = (b << SURTR_LSH) + l;
-        uint2 c = make_uint2(0u, 0u);
-        if (i < n) c = fn(i);
-        uint2 s = wave_incl_scan2(c);
-        if (l == SURTR_LANES - 1u) blk[b] = s;
-    }
-    __syncthreads();
     uint2 carry = make_uint2(0u, 0u);
     for (uint32_t c0 = 0; c0 < nb; c0 += SURTR_WG)
     {
@@ -161,6 +169,26 @@ __device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t&
     totC = carry.x; totW = carry.y;
 }
 
+// Ordered two-level scan over items [0,n): phase 1+2.  fn(i) -> (count, weight).
+// After the call blk[b] holds the exclusive (count, weight) base of 64-block b
+// and (totC, totW) the totals.  Every thread must call it (barriers inside).
+template <class Fn>
+__device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t& totC, uint32_t& totW)
+{
+    const uint32_t nb = (n + SURTR_LANES - 1u) >> SURTR_LSH;
+    const uint32_t l = lane_id(), w = wave_id();
+    for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t i = (b << SURTR_LSH) + l;
+        uint2 c = make_uint2(0u, 0u);
+        if (i < n) c = fn(i);
+        uint2 s = wave_incl_scan2(c);
+        if (l == SURTR_LANES - 1u) blk[b] = s;
+    }
+    __syncthreads();
+    scan_block_array(nb, blk, sh, totC, totW);
+}
+
 // Phase 3 helper: exclusive position of item i inside its 64-block (call with the whole wave).
 __device__ __forceinline__ uint2 wave_excl2(uint2 c)
 {
@@ -183,13 +211,14 @@ __device__ __forceinline__ int comp_of(const Buf& B, int32_t v) { return v < 0 ?
 // Serial tail of one plane (Src/Poly.cpp:367-462) run by one lane when the plane
 // has in-plane vertices or an irregular cap.  Rings of comp 0 / comp 2 vertices
 // have been given room for the insertions; snap = old_neighbors of comp-0 vertices.
-__device__ void relink_serial(Buf& B, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap, Shared& sh)
+__device__ void relink_serial(Buf& B, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
+                              const uint32_t* zlist, uint32_t nz, Shared& sh)
 {
-    for (uint32_t t = 0; t < n1; ++t)
+    // visiting order of :370-373: the new vertices, then the in-plane ones (ascending)
+    const uint32_t M = n1 - n0;
+    for (uint32_t t = 0; t < M + nz; ++t)
     {
-        const uint32_t i = (t + n0) % n1;
-        const int ci = B.comp[i];
-        if (!(ci == 0 || ci == 2)) continue;
+        const uint32_t i = t < M ? n0 + t : zlist[t - M];
         const uint32_t deg = B.llen[i];
         for (uint32_t j = 0; j < deg; ++j)
         {
@@ -276,104 +305,142 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
     *outN = 0; *outBuf = 0; *outH = 0;
+    STAMP_DECL;
 
-    // ---- pre-pass 1: first cutting plane of every original vertex --------
-    for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG) sh.hist[k] = 0;
+    // ---- pre-pass: which original vertices can the sequential algorithm ever touch? ----------
+    // fc(v) = first plane that cuts v (0xFF: none).  A vertex is dropped when every vertex of every
+    // incident face has the same finite fc: those faces are never walked by the relink step and the
+    // vertex only disappears at plane fc (DESIGN.md "band reduction").  Nothing is stored per vertex:
+    // fc of a neighbour is re-derived from its position (planes are tested in order, so "same fc" costs
+    // fc+1 plane evaluations), and the survivors' new indices come from a bit mask + popcounts in LDS.
+    for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG) { sh.hist[k] = 0; sh.zhist[k] = 0; }
     if (tid == 0) { sh.nodrop = 0; sh.flagErr = 0; }
     __syncthreads();
-    {
-        bool zero = false;
-        for (uint32_t v = tid; v < V; v += SURTR_WG)
+    const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
+    unsigned long long* bmask = (nbV <= SURTR_LDS_BLOCKS) ? sh.bmask : S.gmask;
+    uint2* bblk = (nbV <= SURTR_LDS_BLOCKS) ? sh.bblk : S.blk;
+    auto first_cut = [&](float x, float y, float z, bool& zero) -> uint32_t {
+        for (uint32_t k = 0; k < F; ++k)
         {
-            const float x = in.pos[3 * v], y = in.pos[3 * v + 1], z = in.pos[3 * v + 2];
-            uint32_t f = 0xFFu;
-            for (uint32_t k = 0; k < F; ++k)
-            {
-                const int c = side_of(plane_dist(sh.planes[k], x, y, z));
-                if (c == 0) zero = true;
-                if (c < 0) { f = k; break; }
-            }
-            S.fc[v] = (uint8_t)f;
+            const int c = side_of(plane_dist(sh.planes[k], x, y, z));
+            if (c == 0) zero = true;
+            if (c < 0) return k;
         }
-        if (zero) sh.nodrop = 1;     // an original vertex exactly in-plane: keep everything (rare)
-    }
-    __syncthreads();
-    const bool nodrop = sh.nodrop != 0;
-
-    // ---- pre-pass 2: band = vertices whose 1-ring is not uniformly cut by one plane
-    // A vertex may be dropped only if every vertex of every incident face has its first-cut plane:
-    // such faces are never walked by the relink step.  When all incident faces are triangles their
-    // vertices are exactly the 1-ring, otherwise the face loops are walked.
-    auto bandfn = [&](uint32_t v) -> uint2 {
-        const uint32_t f = S.fc[v];
-        const uint32_t deg = in.llen[v];
-        bool keep = nodrop || f == 0xFFu;
-        if (!keep)
+        return 0xFFu;
+    };
+    auto same_fc = [&](int32_t u, uint32_t f) -> bool {
+        const float x = in.pos[3 * u], y = in.pos[3 * u + 1], z = in.pos[3 * u + 2];
+        for (uint32_t k = 0; k < f; ++k)
+            if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
+        return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
+    };
+    {
+        for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
         {
-            const int32_t* r = in.nbr + in.loff[v];
-            for (uint32_t j = 0; j < deg; ++j)
-                if (S.fc[r[j]] != f) { keep = true; break; }
-            if (!keep && !(in.tri != nullptr && in.tri[v]))
+            const uint32_t v = (b << SURTR_LSH) + l;
+            bool keep = false, zero = false; uint32_t deg = 0;
+            if (v < V)
             {
-                for (uint32_t j = 0; j < deg && !keep; ++j)
+                const uint32_t f = first_cut(in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2], zero);
+                deg = in.llen[v];
+                keep = f == 0xFFu;
+                if (!keep)
                 {
-                    int32_t prev = (int32_t)v, cur = r[j];
-                    uint32_t steps = 0;
-                    while (cur != (int32_t)v && steps++ < V)
+                    const int32_t* r = in.nbr + in.loff[v];
+                    // neighbours in groups of 8 with all loads issued before any is used (latency, not bandwidth, rules here)
+                    for (uint32_t j0 = 0; j0 < deg && !keep; j0 += 8)
                     {
-                        if (S.fc[cur] != f) { keep = true; break; }
-                        const int32_t nx = face_next(in.nbr + in.loff[cur], in.llen[cur], prev);
-                        prev = cur; cur = nx;
+                        int32_t u[8]; float ux[8], uy[8], uz[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                        {
+                            const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
+                            ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                        {
+                            if (u[q] < 0) continue;
+                            bool same = true;
+                            for (uint32_t k = 0; k < f && same; ++k)
+                                if (side_of(plane_dist(sh.planes[k], ux[q], uy[q], uz[q])) < 0) same = false;
+                            if (same && !(side_of(plane_dist(sh.planes[f], ux[q], uy[q], uz[q])) < 0)) same = false;
+                            if (!same) keep = true;
+                        }
+                    }
+                    if (!keep && !(in.tri != nullptr && in.tri[v]))
+                    {
+                        for (uint32_t j = 0; j < deg && !keep; ++j)
+                        {
+                            int32_t prev = (int32_t)v, cur = r[j];
+                            uint32_t steps = 0;
+                            while (cur != (int32_t)v && steps++ < V)
+                            {
+                                if (!same_fc(cur, f)) { keep = true; break; }
+                                const int32_t nx = face_next(in.nbr + in.loff[cur], in.llen[cur], prev);
+                                prev = cur; cur = nx;
+                            }
+                        }
+                    }
+                    if (!keep)
+                    {
+                        atomicAdd(&sh.hist[f], 1u);
+                        if (zero)     // in-plane at an earlier plane while alive: it is no "kept" vertex there
+                            for (uint32_t k = 0; k < f; ++k)
+                                if (side_of(plane_dist(sh.planes[k], in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2])) == 0)
+                                    atomicAdd(&sh.zhist[k], 1u);
                     }
                 }
             }
-        }
-        return keep ? make_uint2(1u, deg) : make_uint2(0u, 0u);
-    };
-    uint32_t n = 0, hsum = 0;
-    scan_blocks(V, S.blk, sh, bandfn, n, hsum);
-    if (n > S.CV || hsum > S.CH) return 3;
-    {
-        const uint32_t nb = (V + SURTR_LANES - 1u) >> SURTR_LSH;
-        Buf& A = S.b[0];
-        for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
-        {
-            const uint32_t v = (b << SURTR_LSH) + l;
-            uint2 c = make_uint2(0u, 0u);
-            if (v < V) c = bandfn(v);
-            const uint2 e = wave_excl2(c);
-            if (v < V)
-            {
-                if (c.x)
-                {
-                    const uint2 base = S.blk[b];
-                    const uint32_t id = base.x + e.x;
-                    S.newid[v] = (int32_t)id;
-                    A.pos[3 * id] = in.pos[3 * v]; A.pos[3 * id + 1] = in.pos[3 * v + 1]; A.pos[3 * id + 2] = in.pos[3 * v + 2];
-                    A.loff[id] = base.y + e.y; A.llen[id] = c.y; A.comp[id] = 1;
-                }
-                else
-                {
-                    S.newid[v] = SURTR_SENT;
-                    atomicAdd(&sh.hist[S.fc[v]], 1u);
-                }
-            }
+            const uint2 c = keep ? make_uint2(1u, deg) : make_uint2(0u, 0u);
+            const uint2 inc = wave_incl_scan2(c);
+#ifdef SURTR_EMUL
+            const unsigned long long m = keep ? 1ull : 0ull;
+#else
+            const unsigned long long m = __ballot(keep);
+#endif
+            if (l == SURTR_LANES - 1u) { bblk[b] = inc; bmask[b] = m; }
         }
     }
     __syncthreads();
-    // rings of the reduced solid
+    STAMP(0);
+    uint32_t n = 0, hsum = 0;
+    scan_block_array(nbV, bblk, sh, n, hsum);
+    STAMP(1);
+    if (n > S.CV || hsum > S.CH) return 3;
+    // index of an original vertex in the reduced solid
+    auto newid = [&](int32_t u) -> int32_t {
+        const unsigned long long m = bmask[(uint32_t)u >> SURTR_LSH];
+        const uint32_t bit = (uint32_t)u & (SURTR_LANES - 1u);
+        if (!((m >> bit) & 1ull)) return SURTR_SENT;
+        return (int32_t)(bblk[(uint32_t)u >> SURTR_LSH].x + (uint32_t)__builtin_popcountll(m & ((1ull << bit) - 1ull)));
+    };
     {
         Buf& A = S.b[0];
-        for (uint32_t v = tid; v < V; v += SURTR_WG)
+        for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
         {
-            const int32_t id = S.newid[v];
-            if (id < 0) continue;
-            const int32_t* r = in.nbr + in.loff[v];
-            int32_t* d = A.nbr + A.loff[id];
-            const uint32_t deg = in.llen[v];
-            for (uint32_t j = 0; j < deg; ++j) d[j] = S.newid[r[j]];
+            const unsigned long long m = bmask[b];
+            if (m == 0ull) continue;
+            const uint32_t v = (b << SURTR_LSH) + l;
+            const bool keep = (m >> l) & 1ull;
+            const uint32_t deg = keep ? in.llen[v] : 0u;
+            const uint2 e = wave_excl2(make_uint2(keep ? 1u : 0u, deg));
+            if (keep)
+            {
+                const uint2 base = bblk[b];
+                const uint32_t id = base.x + e.x;
+                A.pos[3 * id] = in.pos[3 * v]; A.pos[3 * id + 1] = in.pos[3 * v + 1]; A.pos[3 * id + 2] = in.pos[3 * v + 2];
+                const uint32_t lo = base.y + e.y;
+                A.loff[id] = lo; A.llen[id] = deg; A.comp[id] = 1;
+                const int32_t* r = in.nbr + in.loff[v];
+                int32_t* d = A.nbr + lo;
+                for (uint32_t j = 0; j < deg; ++j) d[j] = newid(r[j]);
+            }
         }
     }
+    STAMP(2);
     // dropAlive[k] = dropped vertices still alive after plane k = sum_{f>k} hist[f]
     __syncthreads();
     if (tid == 0)
@@ -383,6 +450,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         // hist[k] now = number of dropped vertices with fc > k
     }
     __syncthreads();
+    STAMP(3);
     if (n == 0) return 0;
 
     uint32_t cur = 0;
@@ -408,9 +476,11 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             if (anyz) sh.flagZero = 1;
         }
         __syncthreads();
+        STAMP(4);
         const bool anyCut = sh.flagCut != 0, anyKeep = sh.flagKeep != 0, anyZero = sh.flagZero != 0;
         const uint32_t dropAlive = sh.hist[k];
-        if (!anyCut && !anyKeep && dropAlive == 0)
+        const uint32_t dropKept = dropAlive - sh.zhist[k];   // dropped vertices strictly on the kept side of this plane
+        if (!anyCut && !anyKeep && dropKept == 0)
         {
             // Every vertex is in-plane (e.g. a zero plane from a degenerate hull face).  The reference
             // consults the bounding box first (:296-299): all corners >= 0 skips the plane, anything
@@ -424,6 +494,21 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
                         const float c = B.pos[3 * v + a];
                         lo[a] = c < lo[a] ? c : lo[a]; hi[a] = c > hi[a] ? c : hi[a];
                     }
+                if (dropAlive != 0)
+                {
+                    // dropped vertices still alive (all in-plane here) belong to the box too
+                    for (uint32_t v = 0; v < V; ++v)
+                    {
+                        if ((bmask[v >> SURTR_LSH] >> (v & (SURTR_LANES - 1u))) & 1ull) continue;
+                        bool z0 = false;
+                        if (first_cut(in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2], z0) <= k) continue;
+                        for (int a = 0; a < 3; ++a)
+                        {
+                            const float c = in.pos[3 * v + a];
+                            lo[a] = c < lo[a] ? c : lo[a]; hi[a] = c > hi[a] ? c : hi[a];
+                        }
+                    }
+                }
                 int cmin = 1;
                 for (int q = 0; q < 8; ++q)
                 {
@@ -438,7 +523,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             if (boxAbove) continue;
             n = 0; break;
         }
-        if (!anyKeep && dropAlive == 0) { n = 0; break; }      // "below": everything goes (:322-327)
+        if (!anyKeep && dropKept == 0) { n = 0; break; }       // "below": everything goes (:322-327)
         if (!anyCut)
         {
             // "above" for the reduced solid; dropped vertices may still vanish here (size check :497-499)
@@ -500,6 +585,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         }
         uint32_t hend = hcur + 3u * M;
         __syncthreads();
+        STAMP(5);
 
         // ---- relink (:367-431) ----
         bool serial = anyZero;
@@ -550,8 +636,9 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         }
         if (serial)
         {
+            COUNT(19);
             // give every in-plane vertex a ring with room for insertions plus its snapshot
-            uint32_t* snapoff = S.aux0; uint32_t* cap = S.aux1;
+            uint32_t* snapoff = S.aux0; uint32_t* cap = S.aux1; uint32_t* zlist = S.aux2;
             auto zfn = [&](uint32_t v) -> uint2 {
                 return (B.comp[v] == 0) ? make_uint2(1u, 4u * B.llen[v]) : make_uint2(0u, 0u);
             };
@@ -572,11 +659,12 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
                     const int32_t* src = B.nbr + B.loff[v];
                     for (uint32_t q = 0; q < len; ++q) { B.nbr[dst + q] = src[q]; B.nbr[dst + 2u * len + q] = src[q]; }
                     B.loff[v] = dst; snapoff[v] = dst + 2u * len; cap[v] = 2u * len;
+                    zlist[S.blk[b].x + e.x] = v;
                 }
             }
             hend += zw;
             __syncthreads();
-            if (tid == 0) relink_serial(B, n0, n1, snapoff, cap, sh);
+            if (tid == 0) relink_serial(B, n0, n1, snapoff, cap, zlist, zc, sh);
             __syncthreads();
             if (sh.flagErr) return 2;
             // drop the -1 marks (:426-431), one vertex per lane; then look for two-neighbour vertices
@@ -604,6 +692,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         }
 
         __syncthreads();     // rings and lengths of this plane are final
+        STAMP(6);
         // ---- compaction (:464-495) ----
         Buf& D = S.b[cur ^ 1u];
         auto livefn = [&](uint32_t v) -> uint2 {
@@ -646,6 +735,7 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         }
         __syncthreads();
         if (sh.flagErr) return 2;
+        STAMP(7);
         cur ^= 1u; n = nn; hcur = hh;
         if (n + dropAlive < 4u) { n = 0; break; }
     }

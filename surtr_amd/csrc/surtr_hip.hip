@@ -82,8 +82,7 @@ __device__ static Scratch carve(const ScratchPool& P, uint32_t wg)
     S.aux0 = (uint32_t*)take((size_t)P.CV * 4);
     S.aux1 = (uint32_t*)take((size_t)P.CV * 4);
     S.aux2 = (uint32_t*)take((size_t)P.CV * 4);
-    S.fc = (uint8_t*)take((size_t)P.VMAX);
-    S.newid = (int32_t*)take((size_t)P.VMAX * 4);
+    S.gmask = (unsigned long long*)take((size_t)(P.VMAX / SURTR_LANES + 2) * 8);
     S.blk = (uint2*)take((size_t)P.NB * 8);
     S.CV = P.CV; S.CH = P.CH;
     return S;
@@ -94,7 +93,7 @@ static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX, uint
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t t = 0;
     for (int i = 0; i < 2; ++i) t += r((size_t)CV * 12) + 2 * r((size_t)CV * 4) + r((size_t)CV) + r((size_t)CH * 4);
-    t += 3 * r((size_t)CV * 4) + r((size_t)VMAX) + r((size_t)VMAX * 4) + r((size_t)NB * 8);
+    t += 3 * r((size_t)CV * 4) + r((size_t)(VMAX / SURTR_LANES + 2) * 8) + r((size_t)NB * 8);
     return t;
 }
 
@@ -173,13 +172,22 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
     __shared__ Shared sh;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
+    STAMP_DECL;
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+    const unsigned long long wg_t0 = __builtin_readcyclecounter();
+#endif
     while (true)
     {
         __syncthreads();
+        STAMP(15);
         if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[4], 1u);
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
+        STAMP(8);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long pair_t0 = __builtin_readcyclecounter();
+#endif
         const uint32_t cell = cell_begin + p / P.n, piece = p % P.n;
         PairRec rec;
         memset(&rec, 0, sizeof(rec));
@@ -195,8 +203,10 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
             // Convex first (Src/Surtr.cpp:1466-1468)
             const uint32_t c0 = P.cvo[piece];
             SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0};
+            STAMP(9);
             err = clip_solid(cin, F, S, sh, &cn, &cb, &chn);
             __syncthreads();
+            STAMP(10);
         }
         if (!skip && err == 0 && cn > 0)
         {
@@ -212,8 +222,10 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
             {
                 const uint32_t m0 = P.mvo[piece];
                 SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0};
+                STAMP(11);
                 err = clip_solid(min, F, S, sh, &mn, &mb, &mhn);
                 __syncthreads();
+                STAMP(12);
             }
         }
         if (!skip && err == 0 && cn > 0 && mn > 0)
@@ -244,6 +256,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
                 __syncthreads();     // read before lane 0 clears it again
                 if (!more) break;
             }
+            STAMP(13);
             auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2(lab[v] == v ? 1u : 0u, 0u); };
             uint32_t ni = 0, dum = 0;
             scan_blocks(mn, S.blk, sh, rootfn, ni, dum);
@@ -316,7 +329,14 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
+        STAMP(14);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 10 + 20) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 10) bkt = 10; atomicAdd(&g_stamp[21 + bkt], 1ull); }
+#endif
     }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp[16], d); atomicMax(&g_stamp[17], d); atomicAdd(&g_stamp[18], 1ull); }
+#endif
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -1073,7 +1093,11 @@ int surtr_create(int device, surtr_ctx** out)
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            ctx->max_wg = (uint32_t)prop.multiProcessorCount * 4u;
+        {
+            uint32_t per_cu = SURTR_WG >= 256 ? 4u : (SURTR_WG >= 128 ? 8u : 16u);
+            if (const char* e = getenv("SURTR_WG_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = (uint32_t)v; }
+            ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
+        }
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
     if (hipMalloc((void**)&ctx->arena.cursors, 64) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
@@ -1435,6 +1459,15 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
     HIPCHK(hipGetLastError());
     return SURTR_OK;
 }
+
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+int surtr_debug_stamps(unsigned long long out[32], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+    return SURTR_OK;
+}
+#endif
 
 int surtr_set_profiling(surtr_ctx* ctx, int on)
 {

@@ -145,3 +145,19 @@ def test_capacity_error_is_reported(emul_engine):
         eng.fracture_event(0, 64)
     assert e.value.code == emul_engine.E_CAPACITY
     eng.close()
+
+
+def test_in_plane_vertices_with_band_reduction(emul_engine, oracle):
+    # planes through rows of torus vertices: in-plane (comp == 0) vertices next to dropped regions
+    from surtr_amd import engine, meshgen
+    v, t = meshgen.bumpy_torus(60, 40)
+    mesh = engine.neighbors_from_mesh(v, t)
+    assert (np.abs(v[:, 2]) < 1e-10).sum() > 50
+    eng = emul_engine.Engine(0)
+    for planes in ([[0, 0, 1, 0]], [[0, 0, -1, 0], [1, 0, 0, 0]], [[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, -0.5]],
+                   [[1, 0, 0, -0.2], [0, 0, 1, 0], [0, 0, -1, 0]], [[0, 0, 1, 0], [0, 0, 1, 0]]):
+        pl = np.array(planes, np.float32)
+        a, b = eng.clip_polyhedron(mesh, pl), oracle.clip(mesh, pl)
+        assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]), planes
+        assert np.array_equal(a["pos"], b["pos"]), planes
+    eng.close()
