@@ -169,3 +169,25 @@ def test_repeatable(gpu_engine):
         for k in a:
             assert np.array_equal(a[k], b[k]), k
     eng.close()
+
+
+def test_cpp_host_layer_and_harness(gpu_engine, oracle):
+    """The C++ host layer (reference API names over the C ABI) through the headless harness binary."""
+    import json as js
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "surtr_amd", "host")])
+    exe = os.path.join(root, "surtr_amd", "host", "surtr_harness")
+    out = js.loads(subprocess.check_output([exe, "--mesh", "cube", "--cells", "8"]).decode().strip().splitlines()[-1])
+    sc = scenes.cube_scene(8)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes)
+    assert out["fragments"] == ref["frag_ids"].shape[0] and out["mesh_verts"] == ref["mesh_pos"].shape[0]
+    assert out["indices"] == ref["idx"].shape[0] and out["conv_verts"] == ref["conv_pos"].shape[0]
+    out = js.loads(subprocess.check_output([exe, "--mesh", "torus", "--cells", "256", "--nu", "100", "--nv", "60"]).decode().strip().splitlines()[-1])
+    from surtr_amd import meshgen
+    sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, threads=8)
+    assert out["fragments"] == ref["frag_ids"].shape[0] and out["mesh_verts"] == ref["mesh_pos"].shape[0]
+    assert out["indices"] == ref["idx"].shape[0] and out["mesh_nbrs"] == ref["mesh_nbr"].shape[0]
