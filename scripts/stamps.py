@@ -10,17 +10,17 @@ eng = E.Engine(0)
 eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = eng.fracture_event(0, 4096, flags=flags)
-buf = (ctypes.c_ulonglong * 32)()
+buf = (ctypes.c_ulonglong * 48)()
 L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
-names = ["pre: band mask", "pre: block scan", "pre: emit reduced", "pre: hist", "plane: classify", "plane: new verts", "plane: relink", "plane: compaction",
-         "pair setup", "planes->LDS", "(convex clip total)", "park convex", "(mesh clip total)", "islands label", "islands park", "queue"]
-tot = sum(buf[i] for i in (0,1,2,3,4,5,6,7,8,9,11,13,14,15))
+names = ["pre: band mask", "pre: block scan", "pre: emit reduced", "pre: hist", "plane: classify", "plane: new verts", "plane: relink", "plane: tombstones"]
+tot = sum(buf[i] for i in range(8))
 for i, n in enumerate(names):
     print("%-20s %14d  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
 print("total cycles (lane0, summed over WGs)", tot)
-print("serial planes", buf[19], "nodrop solids", buf[20])
+print("serial planes", buf[19], "solids redone on global scratch", buf[20], "squeezes", buf[31])
+print("overflow causes: toolong %d, n>capV %d, hsum>capEmit %d, M>capAux %d, after squeeze %d, zw %d, ring len %d" % tuple(buf[32:39]))
 print("pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[21 + i] for i in range(11)])
 print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[18], 1), buf[17], buf[18]))
 eng.close()

@@ -5,16 +5,22 @@
 // vertex order, neighbour-ring order and float arithmetic:
 //
 //   pre-pass   every original vertex is classified against all planes of the
-//              cell at once ("first plane that cuts it"); vertices whose whole
-//              1-ring is cut by the same plane can never be touched by the
-//              sequential algorithm and are dropped ("band
-//              reduction" -- a result-preserving cull, not an approximation);
+//              cell at once ("first plane that cuts it"); vertices whose
+//              incident faces are all cut by one and the same plane can never be
+//              touched by the sequential algorithm and are dropped (DESIGN.md
+//              "band reduction" -- a result-preserving cull, not an approximation);
 //   per plane  classify / create edge-cut vertices in (vertex, slot) order by
-//              ballot + prefix sums / relink the cap by face-loop walks /
-//              order-preserving compaction -- the steps of :307-495;
+//              ballot + prefix sums / relink the cap by face-loop walks.  Clipped
+//              vertices stay behind as tombstones: survivors never move, so the
+//              reference's per-plane compaction (:464-495) collapses into ONE
+//              ordered compaction when the solid is written out;
 //   fallback   a plane that puts any vertex exactly in-plane (comp == 0), or any
 //              irregular cap, runs the reference's relink/collapse sequence
 //              literally on one lane of the same workgroup (still on the GPU).
+//
+// Topology (ring offsets/lengths/entries, comp) of the reduced solid lives in
+// LDS with 16-bit indices (Topo<InLds>); a solid that does not fit is redone by
+// the same code on global scratch with 32-bit indices (Topo<InGlobal>).
 //
 // All arithmetic is float32 without contraction (compile with -ffp-contract=off);
 // see oracle/surtr_oracle.cpp for the SimpleMath semantics restated.
@@ -45,7 +51,7 @@
 // Diagnostic build only (-DSURTR_STAMP): lane 0 accumulates s_memtime deltas per phase into a
 // global table that no product code reads.
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-__device__ unsigned long long g_stamp[32];
+__device__ unsigned long long g_stamp[48];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
 #define STAMP(i) do { if (threadIdx.x == 0) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); st_t0 = st_t1; } } while (0)
 #define COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_stamp[i], 1ull); } while (0)
@@ -56,44 +62,71 @@ __device__ unsigned long long g_stamp[32];
 #endif
 
 #define SURTR_MAXF 255
-#define SURTR_SENT (-2)
-#define SURTR_LDS_BLOCKS 1024   // pre-pass masks live in LDS for solids up to 64*1024 vertices
+#define SURTR_DEAD (-3)          // comp of a tombstone
+#define SURTR_OVERFLOW 100       // internal: the solid does not fit this Topo, redo with the larger one
+
+// LDS-resident topology: capacities per workgroup
+#ifndef SURTR_LV
+#define SURTR_LV 5632            // vertex slots
+#endif
+#ifndef SURTR_LH
+#define SURTR_LH 24576           // ring entries (16-bit); LdsTopo + Shared stay under 80 KiB => 2 workgroups per CU
+#endif
 
 namespace surtr {
 
-struct Buf
+// hist[f] += number of active lanes holding f: one LDS atomic per distinct value per wave instead of one per lane.
+__device__ __forceinline__ void wave_hist_add(uint32_t* hist, uint32_t f, bool active)
 {
-    float* pos;       // 3 floats per vertex
-    uint32_t* loff;   // start of the vertex's ring in nbr
-    uint32_t* llen;   // ring length
-    int8_t* comp;     // ComparePlanePoint result of the current plane (2 = created by it)
-    int32_t* nbr;     // ring entries; SURTR_SENT = a dropped original vertex, -1 = marked for removal
+#ifdef SURTR_EMUL
+    if (active) hist[f] += 1u;
+#else
+    unsigned long long todo = __ballot(active);
+    while (todo)
+    {
+        const int leader = __builtin_ctzll(todo);
+        const uint32_t f0 = (uint32_t)__shfl((int)f, leader, 64);
+        const unsigned long long same = __ballot(active && f == f0);
+        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[f0], (uint32_t)__builtin_popcountll(same));
+        todo &= ~same;
+    }
+#endif
+}
+
+struct InLds
+{
+    typedef uint16_t off_t; typedef uint8_t len_t; typedef uint16_t idx_t;
+    static constexpr uint32_t SENT = 0xFFFEu, REM = 0xFFFFu, MAXLEN = 255u;
+};
+struct InGlobal
+{
+    typedef uint32_t off_t; typedef uint32_t len_t; typedef uint32_t idx_t;
+    static constexpr uint32_t SENT = 0xFFFFFFFEu, REM = 0xFFFFFFFFu, MAXLEN = 0x7FFFFFFFu;
 };
 
-struct Scratch
+// The reduced solid of one task.  Slots [0,nS) are vertices in creation order; comp == SURTR_DEAD marks
+// a clipped one.  ring entries >= TT::SENT are not vertices (SENT: a dropped original, REM: marked for removal).
+template <class TT>
+struct Topo
 {
-    Buf b[2];
-    uint32_t* aux0;   // [CV]
-    uint32_t* aux1;   // [CV]
-    uint32_t* aux2;   // [CV]
-    unsigned long long* gmask;   // [VMAX/64] pre-pass band mask when the solid is too big for the LDS copy
-    uint2* blk;       // per-64-block (count, weight) of the ordered scans
-    uint32_t CV, CH;
+    typename TT::off_t* loff; typename TT::len_t* llen; int8_t* comp; typename TT::idx_t* ring;
+    float* pos;                                            // 3 floats per slot (global scratch)
+    uint32_t* succ; uint32_t* pred; uint32_t* pcnt;        // per new vertex of the current plane, global u32[capV] (streamed)
+    uint32_t* aux0; uint32_t* aux1; uint32_t* aux2;        // u32[capV], global scratch
+    uint2* blk;                                            // scan blocks for capV slots
+    uint32_t capV, capH;
+    uint32_t nS, nLive, hUsed;
 };
 
 struct Shared
 {
     float4 planes[SURTR_MAXF + 1];
-    uint32_t hist[SURTR_MAXF + 1];
+    uint32_t hist[SURTR_MAXF + 1];    // after the pre-pass: dropped vertices still alive after plane k
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t wsum[2 * SURTR_NWAVE];
     uint32_t flagCut, flagKeep, flagZero, flagBad, flagErr;
-    uint32_t hend;
-    uint32_t nodrop;
     uint32_t changed;
     uint32_t misc[8];
-    unsigned long long bmask[SURTR_LDS_BLOCKS];   // band bit mask of the pre-pass, one word per 64 vertices
-    uint2 bblk[SURTR_LDS_BLOCKS];                 // (count, ring entries) bases per 64 vertices
 };
 
 // A solid handed to the clipper: positions + (loff, llen) rings with entries local to the solid.
@@ -105,6 +138,7 @@ struct SolidIn
     const int32_t* nbr;     // already offset so that loff indexes it directly
     uint32_t nv;
     const uint8_t* tri;     // per vertex: 1 = every incident face is a triangle (nullptr = unknown)
+    const float* rad;       // per vertex: radius of a ball around it holding every vertex of its incident faces (nullptr = unknown)
 };
 
 __device__ __forceinline__ float plane_dist(const float4 pl, float x, float y, float z)
@@ -138,9 +172,12 @@ __device__ __forceinline__ uint2 wave_incl_scan2(uint2 v)
     return v;
 }
 
-// Ordered two-level scan over items [0,n): phase 1+2.  fn(i) -> (count, weight).
-// After the call blk[b] holds the exclusive (count, weight) base of 64-block b
-// and (totC, totW) the totals.  Every thread must call it (barriers inside).
+__device__ __forceinline__ uint2 wave_excl2(uint2 c)
+{
+    uint2 s = wave_incl_scan2(c);
+    return make_uint2(s.x - c.x, s.y - c.y);
+}
+
 // Exclusive scan, in place, of the per-64-block (count, weight) array; returns the totals.
 __device__ inline void scan_block_array(uint32_t nb, uint2* blk, Shared& sh, uint32_t& totC, uint32_t& totW)
 {
@@ -169,9 +206,9 @@ __device__ inline void scan_block_array(uint32_t nb, uint2* blk, Shared& sh, uin
     totC = carry.x; totW = carry.y;
 }
 
-// Ordered two-level scan over items [0,n): phase 1+2.  fn(i) -> (count, weight).
-// After the call blk[b] holds the exclusive (count, weight) base of 64-block b
-// and (totC, totW) the totals.  Every thread must call it (barriers inside).
+// Ordered two-level scan over items [0,n).  fn(i) -> (count, weight).  Afterwards blk[b] holds the exclusive
+// (count, weight) base of 64-block b; the position inside the block comes from wave_excl2 in the caller's
+// second sweep.  Every thread must call it (barriers inside).
 template <class Fn>
 __device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t& totC, uint32_t& totW)
 {
@@ -189,15 +226,17 @@ __device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t&
     scan_block_array(nb, blk, sh, totC, totW);
 }
 
-// Phase 3 helper: exclusive position of item i inside its 64-block (call with the whole wave).
-__device__ __forceinline__ uint2 wave_excl2(uint2 c)
+// FaceLoop, Src/Poly.cpp:34-41: the ring entry listed just before `prev` (cyclic).
+template <class I>
+__device__ __forceinline__ uint32_t face_next(const I* ring, uint32_t len, uint32_t prev)
 {
-    uint2 s = wave_incl_scan2(c);
-    return make_uint2(s.x - c.x, s.y - c.y);
+    uint32_t k = 0;
+    while (k < len && (uint32_t)ring[k] != prev) ++k;
+    if (k == 0) return (uint32_t)ring[len - 1];
+    return (uint32_t)ring[k - 1];
 }
 
-// FaceLoop, Src/Poly.cpp:34-41.
-__device__ __forceinline__ int32_t face_next(const int32_t* ring, uint32_t len, int32_t prev)
+__device__ __forceinline__ int32_t face_next_in(const int32_t* ring, uint32_t len, int32_t prev)
 {
     uint32_t k = 0;
     while (k < len && ring[k] != prev) ++k;
@@ -205,270 +244,405 @@ __device__ __forceinline__ int32_t face_next(const int32_t* ring, uint32_t len, 
     return ring[k - 1];
 }
 
-__device__ __forceinline__ int comp_of(const Buf& B, int32_t v) { return v < 0 ? 0 : (int)B.comp[v]; }
-
 // ---------------------------------------------------------------------------
-// Serial tail of one plane (Src/Poly.cpp:367-462) run by one lane when the plane
-// has in-plane vertices or an irregular cap.  Rings of comp 0 / comp 2 vertices
-// have been given room for the insertions; snap = old_neighbors of comp-0 vertices.
-__device__ void relink_serial(Buf& B, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
+// Literal relink of one plane (Src/Poly.cpp:367-425) on one lane: the new vertices in creation order,
+// then the in-plane ones ascending (:370-373).  Rings of in-plane vertices were given room for the
+// insertions; snap = old_neighbors of those vertices.
+template <class TT>
+__device__ void relink_serial(Topo<TT>& T, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
                               const uint32_t* zlist, uint32_t nz, Shared& sh)
 {
-    // visiting order of :370-373: the new vertices, then the in-plane ones (ascending)
+    typedef typename TT::idx_t I;
     const uint32_t M = n1 - n0;
     for (uint32_t t = 0; t < M + nz; ++t)
     {
         const uint32_t i = t < M ? n0 + t : zlist[t - M];
-        const uint32_t deg = B.llen[i];
+        const uint32_t deg = T.llen[i];
         for (uint32_t j = 0; j < deg; ++j)
         {
-            int32_t* ri = B.nbr + B.loff[i];
-            const int32_t jn = ri[j];
-            if (jn < 0 || B.comp[jn] != -1) continue;
-            int32_t prev = (int32_t)i, cur = jn;
-            uint32_t steps = 0;
-            while (cur >= 0 && B.comp[cur] == -1 && steps++ < n1)
+            I* ri = T.ring + T.loff[i];
+            const uint32_t jn = ri[j];
+            if (jn >= TT::SENT || T.comp[jn] != -1) continue;
+            uint32_t prev = i, cur = jn, steps = 0;
+            while (cur < TT::SENT && T.comp[cur] == -1 && steps++ < n1)
             {
-                int32_t hold = cur;
-                cur = face_next(B.nbr + B.loff[cur], B.llen[cur], prev);
+                const uint32_t hold = cur;
+                cur = face_next(T.ring + T.loff[cur], T.llen[cur], prev);
                 prev = hold;
             }
-            if (cur < 0) { SURTR_DBG("serial: walk hit sentinel i=%u\n", i); sh.flagErr = 1; return; }
-            if (ri[(j + 1u) % B.llen[i]] == cur || cur == (int32_t)i)
+            if (cur >= TT::SENT) { SURTR_DBG("serial: walk hit a non-vertex i=%u\n", i); sh.flagErr = 1; return; }
+            if ((uint32_t)ri[(j + 1u) % T.llen[i]] == cur || cur == i)
             {
-                ri[j] = -1;
+                ri[j] = (I)TT::REM;
             }
             else
             {
-                ri[j] = cur;
-                int32_t* rc = B.nbr + B.loff[cur];
-                const uint32_t lc = B.llen[cur];
-                if (B.comp[cur] == 2)
+                ri[j] = (I)cur;
+                I* rc = T.ring + T.loff[cur];
+                const uint32_t lc = T.llen[cur];
+                if (T.comp[cur] == 2)
                 {
-                    if (lc >= 3u) { SURTR_DBG("serial: comp2 ring full cur=%d i=%u n0=%u n1=%u\n", cur, i, n0, n1); sh.flagErr = 1; return; }     // room reserved for one insertion only
+                    if (lc >= 3u) { SURTR_DBG("serial: comp2 ring full cur=%u\n", cur); sh.flagErr = 1; return; }
                     for (uint32_t q = lc; q > 0; --q) rc[q] = rc[q - 1];
-                    rc[0] = (int32_t)i;
-                    B.llen[cur] = lc + 1;
+                    rc[0] = (I)i;
+                    T.llen[cur] = (typename TT::len_t)(lc + 1);
                 }
-                else if (B.comp[cur] == 0 && (uint32_t)cur < n0)
+                else if (T.comp[cur] == 0 && cur < n0)
                 {
-                    if (lc >= cap[cur]) { SURTR_DBG("serial: comp0 ring full cur=%d\n", cur); sh.flagErr = 1; return; }
-                    int32_t* sn = B.nbr + snapoff[cur];
+                    if (lc >= cap[cur]) { SURTR_DBG("serial: comp0 ring full cur=%u\n", cur); sh.flagErr = 1; return; }
+                    I* sn = T.ring + snapoff[cur];
                     uint32_t at = 0;
-                    while (at < lc && sn[at] != prev) ++at;
+                    while (at < lc && (uint32_t)sn[at] != prev) ++at;
                     for (uint32_t q = lc; q > at; --q) { rc[q] = rc[q - 1]; sn[q] = sn[q - 1]; }
-                    rc[at] = (int32_t)i; sn[at] = (int32_t)i;
-                    B.llen[cur] = lc + 1;
+                    rc[at] = (I)i; sn[at] = (I)i;
+                    T.llen[cur] = (typename TT::len_t)(lc + 1);
                 }
-                else { SURTR_DBG("serial: walk ended on comp %d vertex %d (i=%u j=%u n0=%u n1=%u steps=%u)\n", (int)B.comp[cur], cur, i, j, n0, n1, steps); sh.flagErr = 1; return; }   // walk ended on a kept or clipped vertex
+                else { SURTR_DBG("serial: walk ended on comp %d vertex %u\n", (int)T.comp[cur], cur); sh.flagErr = 1; return; }
             }
         }
     }
 }
 
 // Two-neighbour vertices, Src/Poly.cpp:433-462, literal and serial (rare).
-__device__ void collapse_serial(Buf& B, uint32_t n1)
+template <class TT>
+__device__ void collapse_serial(Topo<TT>& T, uint32_t n1)
 {
+    typedef typename TT::idx_t I;
     bool again = true;
     while (again)
     {
         again = false;
         for (uint32_t i = 0; i < n1; ++i)
         {
-            if (B.comp[i] >= 0 && B.llen[i] == 2u)
+            if (T.comp[i] >= 0 && T.llen[i] == 2u)
             {
                 again = true;
-                const int32_t a = B.nbr[B.loff[i]], b = B.nbr[B.loff[i] + 1];
-                if (a >= 0)
+                const uint32_t a = T.ring[T.loff[i]], b = T.ring[T.loff[i] + 1];
+                if (a < TT::SENT)
                 {
-                    int32_t* ra = B.nbr + B.loff[a];
-                    for (uint32_t q = 0; q < B.llen[a]; ++q) if (ra[q] == (int32_t)i) { ra[q] = b; break; }
+                    I* ra = T.ring + T.loff[a];
+                    for (uint32_t q = 0; q < T.llen[a]; ++q) if ((uint32_t)ra[q] == i) { ra[q] = (I)b; break; }
                 }
-                if (b >= 0)
+                if (b < TT::SENT)
                 {
-                    int32_t* rb = B.nbr + B.loff[b];
-                    for (uint32_t q = 0; q < B.llen[b]; ++q) if (rb[q] == (int32_t)i) { rb[q] = a; break; }
+                    I* rb = T.ring + T.loff[b];
+                    for (uint32_t q = 0; q < T.llen[b]; ++q) if ((uint32_t)rb[q] == i) { rb[q] = (I)a; break; }
                 }
-                B.comp[i] = -1;
+                T.comp[i] = -1;
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Clips `in` by sh.planes[0..F).  The result is left in S.b[*outBuf] with
-// *outN vertices (0 = empty) and rings packed in vertex order (loff is the
-// exclusive scan of llen).  Returns 0 or an error code (uniform over the group).
-__device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared& sh, uint32_t* outN, uint32_t* outBuf,
-                          uint32_t* outH)
+// Pre-pass: builds the reduced solid of `in` for the planes sh.planes[0..F) in T.
+// bmask/bblk: one word / one (count, ring entries) pair per 64 input vertices (LDS or global).
+// capH_emit: ring entries available while the masks are still in use.
+// Returns 0 or SURTR_OVERFLOW (does not fit T) -- uniform over the workgroup.
+template <class TT>
+__device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh, unsigned long long* bmask, uint2* bblk,
+                       uint32_t capH_emit, unsigned long long* spill_mask, uint2* spill_blk)
 {
+    typedef typename TT::idx_t I;
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
-    *outN = 0; *outBuf = 0; *outH = 0;
     STAMP_DECL;
-
-    // ---- pre-pass: which original vertices can the sequential algorithm ever touch? ----------
-    // fc(v) = first plane that cuts v (0xFF: none).  A vertex is dropped when every vertex of every
-    // incident face has the same finite fc: those faces are never walked by the relink step and the
-    // vertex only disappears at plane fc (DESIGN.md "band reduction").  Nothing is stored per vertex:
-    // fc of a neighbour is re-derived from its position (planes are tested in order, so "same fc" costs
-    // fc+1 plane evaluations), and the survivors' new indices come from a bit mask + popcounts in LDS.
     for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG) { sh.hist[k] = 0; sh.zhist[k] = 0; }
-    if (tid == 0) { sh.nodrop = 0; sh.flagErr = 0; }
+    if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; sh.misc[3] = 0; }
     __syncthreads();
     const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
-    unsigned long long* bmask = (nbV <= SURTR_LDS_BLOCKS) ? sh.bmask : S.gmask;
-    uint2* bblk = (nbV <= SURTR_LDS_BLOCKS) ? sh.bblk : S.blk;
-    auto first_cut = [&](float x, float y, float z, bool& zero) -> uint32_t {
-        for (uint32_t k = 0; k < F; ++k)
-        {
-            const int c = side_of(plane_dist(sh.planes[k], x, y, z));
-            if (c == 0) zero = true;
-            if (c < 0) return k;
-        }
-        return 0xFFu;
-    };
-    auto same_fc = [&](int32_t u, uint32_t f) -> bool {
-        const float x = in.pos[3 * u], y = in.pos[3 * u + 1], z = in.pos[3 * u + 2];
-        for (uint32_t k = 0; k < f; ++k)
-            if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
-        return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
-    };
+    uint32_t* needy = T.aux0;      // work list of vertices that need the exact neighbour test: v | fc << 24
+    uint32_t* orig = T.aux1;       // reduced index -> original vertex
+
+    // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
+    // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
+    // to and including fc(v), all those vertices have the same fc and v is dropped right here.
+    for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
     {
-        for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
+        const uint32_t v = (b << SURTR_LSH) + l;
+        bool keep = false, need = false, drop = false; uint32_t f = 0xFFu;
+        if (v < V)
         {
-            const uint32_t v = (b << SURTR_LSH) + l;
-            bool keep = false, zero = false; uint32_t deg = 0;
-            if (v < V)
+            const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+            const float rv = (in.rad != nullptr && V < (1u << 24)) ? in.rad[v] : -1.f;
+            const float mag = fabsf(px) + fabsf(py) + fabsf(pz);
+            bool ballClear = rv >= 0.f;
+            for (uint32_t k = 0; k < F; ++k)
             {
-                const uint32_t f = first_cut(in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2], zero);
-                deg = in.llen[v];
-                keep = f == 0xFFu;
-                if (!keep)
+                const float4 pk = sh.planes[k];
+                const float sk = plane_dist(pk, px, py, pz);
+                const int c = side_of(sk);
+                if (ballClear)
                 {
-                    const int32_t* r = in.nbr + in.loff[v];
-                    // neighbours in groups of 8 with all loads issued before any is used (latency, not bandwidth, rules here)
-                    for (uint32_t j0 = 0; j0 < deg && !keep; j0 += 8)
-                    {
-                        int32_t u[8]; float ux[8], uy[8], uz[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                        {
-                            const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
-                            ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                        {
-                            if (u[q] < 0) continue;
-                            bool same = true;
-                            for (uint32_t k = 0; k < f && same; ++k)
-                                if (side_of(plane_dist(sh.planes[k], ux[q], uy[q], uz[q])) < 0) same = false;
-                            if (same && !(side_of(plane_dist(sh.planes[f], ux[q], uy[q], uz[q])) < 0)) same = false;
-                            if (!same) keep = true;
-                        }
-                    }
-                    if (!keep && !(in.tri != nullptr && in.tri[v]))
-                    {
-                        for (uint32_t j = 0; j < deg && !keep; ++j)
-                        {
-                            int32_t prev = (int32_t)v, cur = r[j];
-                            uint32_t steps = 0;
-                            while (cur != (int32_t)v && steps++ < V)
-                            {
-                                if (!same_fc(cur, f)) { keep = true; break; }
-                                const int32_t nx = face_next(in.nbr + in.loff[cur], in.llen[cur], prev);
-                                prev = cur; cur = nx;
-                            }
-                        }
-                    }
-                    if (!keep)
-                    {
-                        atomicAdd(&sh.hist[f], 1u);
-                        if (zero)     // in-plane at an earlier plane while alive: it is no "kept" vertex there
-                            for (uint32_t k = 0; k < f; ++k)
-                                if (side_of(plane_dist(sh.planes[k], in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2])) == 0)
-                                    atomicAdd(&sh.zhist[k], 1u);
-                    }
+                    const float nl = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);            // >= |n|
+                    const float margin = rv * nl * 1.001f + 1.0e-5f * (fabsf(pk.w) + nl * (mag + rv));
+                    if (!(fabsf(sk) > margin)) ballClear = false;
                 }
+                if (c < 0) { f = k; break; }
             }
-            const uint2 c = keep ? make_uint2(1u, deg) : make_uint2(0u, 0u);
-            const uint2 inc = wave_incl_scan2(c);
+            keep = f == 0xFFu;
+            drop = !keep && ballClear;      // cannot be in-plane anywhere before fc (|s| > margin there)
+            need = !keep && !ballClear;
+        }
+        wave_hist_add(sh.hist, f, drop);
 #ifdef SURTR_EMUL
-            const unsigned long long m = keep ? 1ull : 0ull;
+        const unsigned long long mk = keep ? 1ull : 0ull, mn = need ? 1ull : 0ull;
 #else
-            const unsigned long long m = __ballot(keep);
+        const unsigned long long mk = __ballot(keep), mn = __ballot(need);
 #endif
-            if (l == SURTR_LANES - 1u) { bblk[b] = inc; bmask[b] = m; }
+        if (l == 0) bmask[b] = mk;
+        if (mn)
+        {
+            uint32_t base = 0;
+            if (l == 0) base = atomicAdd(&sh.misc[3], (uint32_t)__builtin_popcountll(mn));
+            base = (uint32_t)__shfl((int)base, 0, SURTR_LANES);
+            if (need) needy[base + (uint32_t)__builtin_popcountll(mn & ((1ull << l) - 1ull))] = v | (f << 24);
         }
     }
     __syncthreads();
     STAMP(0);
-    uint32_t n = 0, hsum = 0;
-    scan_block_array(nbV, bblk, sh, n, hsum);
-    STAMP(1);
-    if (n > S.CV || hsum > S.CH) return 3;
-    // index of an original vertex in the reduced solid
-    auto newid = [&](int32_t u) -> int32_t {
-        const unsigned long long m = bmask[(uint32_t)u >> SURTR_LSH];
-        const uint32_t bit = (uint32_t)u & (SURTR_LANES - 1u);
-        if (!((m >> bit) & 1ull)) return SURTR_SENT;
-        return (int32_t)(bblk[(uint32_t)u >> SURTR_LSH].x + (uint32_t)__builtin_popcountll(m & ((1ull << bit) - 1ull)));
-    };
+    // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
+    const uint32_t nNeedy = sh.misc[3];
+    for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += SURTR_WG)
     {
-        Buf& A = S.b[0];
+        const uint32_t i = i0 + l;
+        bool keep = false, drop = false, zero = false; uint32_t f = 0, v = 0;
+        if (i < nNeedy)
+        {
+            const uint32_t e = needy[i];
+            v = e & 0xFFFFFFu; f = e >> 24;
+            const uint32_t deg = in.llen[v];
+            const int32_t* r = in.nbr + in.loff[v];
+            auto same_fc = [&](float x, float y, float z) -> bool {
+                for (uint32_t k = 0; k < f; ++k)
+                    if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
+                return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
+            };
+            for (uint32_t j0 = 0; j0 < deg && !keep; j0 += 8)
+            {
+                int32_t u[8]; float ux[8], uy[8], uz[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                {
+                    const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
+                    ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (u[q] >= 0 && !same_fc(ux[q], uy[q], uz[q])) keep = true;
+            }
+            if (!keep && !(in.tri != nullptr && in.tri[v]))
+            {
+                // faces that are not triangles: walk every incident face loop
+                for (uint32_t j = 0; j < deg && !keep; ++j)
+                {
+                    int32_t prev = (int32_t)v, cur = r[j];
+                    uint32_t steps = 0;
+                    while (cur != (int32_t)v && steps++ < V)
+                    {
+                        if (!same_fc(in.pos[3 * cur], in.pos[3 * cur + 1], in.pos[3 * cur + 2])) { keep = true; break; }
+                        const int32_t nx = face_next_in(in.nbr + in.loff[cur], in.llen[cur], prev);
+                        prev = cur; cur = nx;
+                    }
+                }
+            }
+            drop = !keep;
+            if (keep)
+            {
+#ifdef SURTR_EMUL
+                bmask[v >> SURTR_LSH] |= 1ull << (v & (SURTR_LANES - 1u));
+#else
+                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
+#endif
+            }
+            else
+            {
+                // in-plane at an earlier plane while alive: it is no "kept" vertex there
+                const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+                for (uint32_t k = 0; k < f; ++k)
+                    if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) { zero = true; atomicAdd(&sh.zhist[k], 1u); }
+            }
+        }
+        (void)zero;
+        wave_hist_add(sh.hist, f, drop);
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---- A3: per 64-block (kept vertices, their ring entries) ----
+    {
+        bool toolong = false;
         for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
         {
             const unsigned long long m = bmask[b];
-            if (m == 0ull) continue;
-            const uint32_t v = (b << SURTR_LSH) + l;
-            const bool keep = (m >> l) & 1ull;
-            const uint32_t deg = keep ? in.llen[v] : 0u;
-            const uint2 e = wave_excl2(make_uint2(keep ? 1u : 0u, deg));
-            if (keep)
+            uint2 inc = make_uint2(0u, 0u);
+            if (m != 0ull)
             {
-                const uint2 base = bblk[b];
-                const uint32_t id = base.x + e.x;
-                A.pos[3 * id] = in.pos[3 * v]; A.pos[3 * id + 1] = in.pos[3 * v + 1]; A.pos[3 * id + 2] = in.pos[3 * v + 2];
-                const uint32_t lo = base.y + e.y;
-                A.loff[id] = lo; A.llen[id] = deg; A.comp[id] = 1;
-                const int32_t* r = in.nbr + in.loff[v];
-                int32_t* d = A.nbr + lo;
-                for (uint32_t j = 0; j < deg; ++j) d[j] = newid(r[j]);
+                const uint32_t v = (b << SURTR_LSH) + l;
+                const bool keep = (m >> l) & 1ull;
+                const uint32_t deg = keep ? in.llen[v] : 0u;
+                if (deg > TT::MAXLEN / 2u) toolong = true;
+                inc = wave_incl_scan2(make_uint2(keep ? 1u : 0u, deg));
             }
+            if (l == SURTR_LANES - 1u) bblk[b] = inc;
+        }
+        if (toolong) sh.flagBad = 1;
+    }
+    __syncthreads();
+    uint32_t n = 0, hsum = 0;
+    scan_block_array(nbV, bblk, sh, n, hsum);
+    const bool toolong = sh.flagBad != 0;
+    __syncthreads();
+    if (spill_mask != nullptr && spill_mask != bmask)
+    {
+        // a global copy of the bit mask always exists (clip_planes' all-in-plane corner case reads it).  The LDS
+        // masks share the tail of the ring area; a band that needs all of it moves both mask arrays to global scratch.
+        const bool spill = hsum > capH_emit && hsum <= T.capH;
+        for (uint32_t b = tid; b < nbV; b += SURTR_WG) { spill_mask[b] = bmask[b]; if (spill) spill_blk[b] = bblk[b]; }
+        __syncthreads();
+        if (spill) { bmask = spill_mask; bblk = spill_blk; capH_emit = T.capH; }
+    }
+    if (toolong) COUNT(32);
+    if (n > T.capV) COUNT(33);
+    if (hsum > capH_emit) COUNT(34);
+    if (toolong || n > T.capV || hsum > capH_emit || n >= TT::SENT) return SURTR_OVERFLOW;
+    // ---- emit: slot table first (sparse sweep, no gathers), then rings densely over the kept vertices ----
+    for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
+    {
+        const unsigned long long m = bmask[b];
+        if (m == 0ull) continue;
+        const uint32_t v = (b << SURTR_LSH) + l;
+        const bool keep = (m >> l) & 1ull;
+        const uint32_t deg = keep ? in.llen[v] : 0u;
+        const uint2 e = wave_excl2(make_uint2(keep ? 1u : 0u, deg));
+        if (keep)
+        {
+            const uint2 base = bblk[b];
+            const uint32_t id = base.x + e.x;
+            orig[id] = v;
+            T.loff[id] = (typename TT::off_t)(base.y + e.y); T.llen[id] = (typename TT::len_t)deg; T.comp[id] = 1;
+        }
+    }
+    __syncthreads();
+    // index of an original vertex in the reduced solid
+    auto newid = [&](int32_t u) -> uint32_t {
+        const unsigned long long m = bmask[(uint32_t)u >> SURTR_LSH];
+        const uint32_t bit = (uint32_t)u & (SURTR_LANES - 1u);
+        if (!((m >> bit) & 1ull)) return TT::SENT;
+        return bblk[(uint32_t)u >> SURTR_LSH].x + (uint32_t)__builtin_popcountll(m & ((1ull << bit) - 1ull));
+    };
+    for (uint32_t id = tid; id < n; id += SURTR_WG)
+    {
+        const uint32_t v = orig[id];
+        T.pos[3 * id] = in.pos[3 * v]; T.pos[3 * id + 1] = in.pos[3 * v + 1]; T.pos[3 * id + 2] = in.pos[3 * v + 2];
+        const uint32_t deg = T.llen[id];
+        const int32_t* r = in.nbr + in.loff[v];
+        I* d = T.ring + T.loff[id];
+        for (uint32_t j0 = 0; j0 < deg; j0 += 8)
+        {
+            int32_t u[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (u[q] >= 0) d[j0 + q] = (I)newid(u[q]);
         }
     }
     STAMP(2);
-    // dropAlive[k] = dropped vertices still alive after plane k = sum_{f>k} hist[f]
+    // hist[k] := dropped vertices still alive after plane k = sum_{f>k} hist[f]
     __syncthreads();
     if (tid == 0)
     {
         uint32_t run = 0;
         for (int k = (int)F - 1; k >= 0; --k) { const uint32_t h = sh.hist[k]; sh.hist[k] = run; run += h; }
-        // hist[k] now = number of dropped vertices with fc > k
     }
     __syncthreads();
     STAMP(3);
-    if (n == 0) return 0;
+    T.nS = n; T.nLive = n; T.hUsed = hsum;
+    return 0;
+}
 
-    uint32_t cur = 0;
-    uint32_t hcur = hsum;
+// Global scratch used to squeeze tombstones out of a Topo (any variant) without in-place hazards.
+struct SqueezeTmp
+{
+    float* pos; uint32_t* loff; uint32_t* llen; int8_t* comp; uint32_t* ring;
+};
+
+// Order-preserving removal of the tombstones: live slots move down, rings are renumbered.  comp values of
+// the current plane are kept, so it may run between classification and edge cutting.
+template <class TT>
+__device__ void squeeze(Topo<TT>& T, Shared& sh, const SqueezeTmp tmp)
+{
+    typedef typename TT::idx_t I;
+    COUNT(31);
+    auto livefn = [&](uint32_t v) -> uint2 {
+        return (T.comp[v] != SURTR_DEAD) ? make_uint2(1u, (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
+    };
+    uint32_t nn = 0, hh = 0;
+    scan_blocks(T.nS, T.blk, sh, livefn, nn, hh);
+    const uint32_t nb = (T.nS + SURTR_LANES - 1u) >> SURTR_LSH;
+    uint32_t* idmap = T.aux0;
+    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t v = (b << SURTR_LSH) + lane_id();
+        uint2 c = make_uint2(0u, 0u);
+        if (v < T.nS) c = livefn(v);
+        const uint2 e = wave_excl2(c);
+        if (v < T.nS && c.x)
+        {
+            const uint32_t id = T.blk[b].x + e.x;
+            idmap[v] = id;
+            tmp.pos[3 * id] = T.pos[3 * v]; tmp.pos[3 * id + 1] = T.pos[3 * v + 1]; tmp.pos[3 * id + 2] = T.pos[3 * v + 2];
+            tmp.loff[id] = T.blk[b].y + e.y; tmp.llen[id] = c.y; tmp.comp[id] = T.comp[v];
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < T.nS; v += SURTR_WG)
+    {
+        if (T.comp[v] == SURTR_DEAD) continue;
+        const I* r = T.ring + T.loff[v];
+        uint32_t* d = tmp.ring + tmp.loff[idmap[v]];
+        const uint32_t len = T.llen[v];
+        for (uint32_t q = 0; q < len; ++q) { const uint32_t u = r[q]; d[q] = u >= TT::SENT ? u : idmap[u]; }
+    }
+    __syncthreads();
+    for (uint32_t v = threadIdx.x; v < nn; v += SURTR_WG)
+    {
+        T.pos[3 * v] = tmp.pos[3 * v]; T.pos[3 * v + 1] = tmp.pos[3 * v + 1]; T.pos[3 * v + 2] = tmp.pos[3 * v + 2];
+        T.loff[v] = (typename TT::off_t)tmp.loff[v]; T.llen[v] = (typename TT::len_t)tmp.llen[v]; T.comp[v] = tmp.comp[v];
+    }
+    for (uint32_t e = threadIdx.x; e < hh; e += SURTR_WG) T.ring[e] = (I)tmp.ring[e];
+    T.nS = nn; T.hUsed = hh;
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// The plane loop on a reduced solid.  `in`/`bmask` are only consulted in the all-in-plane corner case.
+// Returns 0 (T.nLive == 0: empty), an error code, or SURTR_OVERFLOW.
+template <class TT>
+__device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const SolidIn in, const unsigned long long* bmask,
+                           const SqueezeTmp tmp)
+{
+    typedef typename TT::idx_t I;
+    const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
+    STAMP_DECL;
+    if (T.nLive == 0) return 0;
+    bool squeezed = false;
     for (uint32_t k = 0; k < F; ++k)
     {
-        Buf& B = S.b[cur];
         const float4 pl = sh.planes[k];
+        const uint32_t nS = T.nS;
         __syncthreads();     // every lane has read the previous plane's flags before they are reset
         if (tid == 0) { sh.flagCut = 0; sh.flagKeep = 0; sh.flagZero = 0; sh.flagBad = 0; }
         __syncthreads();
         // ---- classify (:307-318) ----
         {
             bool anyc = false, anyk = false, anyz = false;
-            for (uint32_t v = tid; v < n; v += SURTR_WG)
+            for (uint32_t v = tid; v < nS; v += SURTR_WG)
             {
-                const int c = side_of(plane_dist(pl, B.pos[3 * v], B.pos[3 * v + 1], B.pos[3 * v + 2]));
-                B.comp[v] = (int8_t)c;
+                if (T.comp[v] == SURTR_DEAD) continue;
+                const int c = side_of(plane_dist(pl, T.pos[3 * v], T.pos[3 * v + 1], T.pos[3 * v + 2]));
+                T.comp[v] = (int8_t)c;
                 anyc |= c < 0; anyk |= c > 0; anyz |= c == 0;
             }
             if (anyc) sh.flagCut = 1;
@@ -487,26 +661,27 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             // else ends in "below" (:322-327).
             if (tid == 0)
             {
-                float lo[3] = {B.pos[0], B.pos[1], B.pos[2]}, hi[3] = {B.pos[0], B.pos[1], B.pos[2]};
-                for (uint32_t v = 1; v < n; ++v)
+                float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+                bool first = true;
+                auto grow = [&](const float* p) {
                     for (int a = 0; a < 3; ++a)
                     {
-                        const float c = B.pos[3 * v + a];
-                        lo[a] = c < lo[a] ? c : lo[a]; hi[a] = c > hi[a] ? c : hi[a];
+                        if (first) { lo[a] = p[a]; hi[a] = p[a]; }
+                        else { lo[a] = p[a] < lo[a] ? p[a] : lo[a]; hi[a] = p[a] > hi[a] ? p[a] : hi[a]; }
                     }
+                    first = false;
+                };
+                for (uint32_t v = 0; v < nS; ++v) if (T.comp[v] != SURTR_DEAD) grow(T.pos + 3 * v);
                 if (dropAlive != 0)
                 {
                     // dropped vertices still alive (all in-plane here) belong to the box too
-                    for (uint32_t v = 0; v < V; ++v)
+                    for (uint32_t v = 0; v < in.nv; ++v)
                     {
                         if ((bmask[v >> SURTR_LSH] >> (v & (SURTR_LANES - 1u))) & 1ull) continue;
-                        bool z0 = false;
-                        if (first_cut(in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2], z0) <= k) continue;
-                        for (int a = 0; a < 3; ++a)
-                        {
-                            const float c = in.pos[3 * v + a];
-                            lo[a] = c < lo[a] ? c : lo[a]; hi[a] = c > hi[a] ? c : hi[a];
-                        }
+                        bool cutBefore = false;
+                        for (uint32_t q = 0; q <= k && !cutBefore; ++q)
+                            if (side_of(plane_dist(sh.planes[q], in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2])) < 0) cutBefore = true;
+                        if (!cutBefore) grow(in.pos + 3 * v);
                     }
                 }
                 int cmin = 1;
@@ -521,30 +696,41 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             const bool boxAbove = sh.misc[0] != 0;
             __syncthreads();
             if (boxAbove) continue;
-            n = 0; break;
+            T.nLive = 0; break;
         }
-        if (!anyKeep && dropKept == 0) { n = 0; break; }       // "below": everything goes (:322-327)
+        if (!anyKeep && dropKept == 0) { T.nLive = 0; break; }     // "below": everything goes (:322-327)
         if (!anyCut)
         {
             // "above" for the reduced solid; dropped vertices may still vanish here (size check :497-499)
-            if (n + dropAlive < 4u) { n = 0; break; }
+            if (T.nLive + dropAlive < 4u) { T.nLive = 0; break; }
             continue;
         }
 
         // ---- new vertices on straddling edges, in (vertex, slot) order (:333-357) ----
         auto cutfn = [&](uint32_t v) -> uint2 {
-            if (B.comp[v] >= 0) return make_uint2(0u, 0u);
-            const int32_t* r = B.nbr + B.loff[v];
-            const uint32_t deg = B.llen[v];
+            if (T.comp[v] != -1) return make_uint2(0u, 0u);
+            const I* r = T.ring + T.loff[v];
+            const uint32_t deg = T.llen[v];
             uint32_t c = 0;
-            for (uint32_t j = 0; j < deg; ++j) { const int32_t u = r[j]; if (u >= 0 && B.comp[u] > 0) ++c; }
-            return make_uint2(c, 0u);
+            for (uint32_t j = 0; j < deg; ++j) { const uint32_t u = r[j]; if (u < TT::SENT && T.comp[u] > 0) ++c; }
+            return make_uint2(c, 1u);
         };
-        uint32_t M = 0, dummy = 0;
-        scan_blocks(n, S.blk, sh, cutfn, M, dummy);
-        const uint32_t n0 = n, n1 = n + M;
-        if (n1 > S.CV || hcur + 3u * M > S.CH) return 3;
+        uint32_t M = 0, nCut = 0;
+        scan_blocks(nS, T.blk, sh, cutfn, M, nCut);
+        if (nS + M > T.capV || T.hUsed + 3u * M + (anyZero ? T.hUsed : 0u) > T.capH || nS + M >= TT::SENT)
         {
+            // out of slots: squeeze the tombstones out (order-preserving, like :464-495) and retry this plane once
+            if (squeezed) { COUNT(36); return SURTR_OVERFLOW; }
+            squeeze(T, sh, tmp);
+            squeezed = true;
+            --k;
+            continue;
+        }
+        squeezed = false;
+        const uint32_t n0 = nS, n1 = nS + M;
+        {
+            // sparse sweep (LDS only): which (clipped vertex, slot) makes new vertex n0 + t, in reference order
+            uint32_t* srcv = T.succ; uint32_t* srcj = T.pred;
             const uint32_t nb = (n0 + SURTR_LANES - 1u) >> SURTR_LSH;
             for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
             {
@@ -554,36 +740,44 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
                 const uint2 e = wave_excl2(c);
                 if (v < n0 && c.x)
                 {
-                    uint32_t fresh = n0 + S.blk[b].x + e.x;
-                    int32_t* r = B.nbr + B.loff[v];
-                    const uint32_t deg = B.llen[v];
-                    const float ax = B.pos[3 * v], ay = B.pos[3 * v + 1], az = B.pos[3 * v + 2];
-                    const float sa = plane_dist(pl, ax, ay, az);
+                    uint32_t t = T.blk[b].x + e.x;
+                    const I* r = T.ring + T.loff[v];
+                    const uint32_t deg = T.llen[v];
                     for (uint32_t j = 0; j < deg; ++j)
                     {
-                        const int32_t u = r[j];
-                        if (u < 0 || B.comp[u] <= 0) continue;
-                        const float bx = B.pos[3 * u], by = B.pos[3 * u + 1], bz = B.pos[3 * u + 2];
-                        const float sb = plane_dist(pl, bx, by, bz);
-                        // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
-                        const float inv = 1.f / (sb - sa);
-                        B.pos[3 * fresh] = (ax * sb - bx * sa) * inv;
-                        B.pos[3 * fresh + 1] = (ay * sb - by * sa) * inv;
-                        B.pos[3 * fresh + 2] = (az * sb - bz * sa) * inv;
-                        B.comp[fresh] = 2;
-                        const uint32_t lo = hcur + 3u * (fresh - n0);
-                        B.loff[fresh] = lo; B.llen[fresh] = 2;
-                        B.nbr[lo] = (int32_t)v; B.nbr[lo + 1] = u; B.nbr[lo + 2] = -1;
-                        int32_t* ru = B.nbr + B.loff[u];
-                        const uint32_t du = B.llen[u];
-                        for (uint32_t q = 0; q < du; ++q) if (ru[q] == (int32_t)v) { ru[q] = (int32_t)fresh; break; }
-                        r[j] = (int32_t)fresh;
-                        ++fresh;
+                        const uint32_t u = r[j];
+                        if (u >= TT::SENT || T.comp[u] <= 0) continue;
+                        srcv[t] = v; srcj[t] = j; ++t;
                     }
                 }
             }
+            __syncthreads();
+            // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
+            for (uint32_t t = tid; t < M; t += SURTR_WG)
+            {
+                const uint32_t v = srcv[t], j = srcj[t], fresh = n0 + t;
+                I* r = T.ring + T.loff[v];
+                const uint32_t u = r[j];
+                const float ax = T.pos[3 * v], ay = T.pos[3 * v + 1], az = T.pos[3 * v + 2];
+                const float bx = T.pos[3 * u], by = T.pos[3 * u + 1], bz = T.pos[3 * u + 2];
+                const float sa = plane_dist(pl, ax, ay, az);
+                const float sb = plane_dist(pl, bx, by, bz);
+                // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
+                const float inv = 1.f / (sb - sa);
+                T.pos[3 * fresh] = (ax * sb - bx * sa) * inv;
+                T.pos[3 * fresh + 1] = (ay * sb - by * sa) * inv;
+                T.pos[3 * fresh + 2] = (az * sb - bz * sa) * inv;
+                T.comp[fresh] = 2;
+                const uint32_t lo = T.hUsed + 3u * t;
+                T.loff[fresh] = (typename TT::off_t)lo; T.llen[fresh] = 2;
+                T.ring[lo] = (I)v; T.ring[lo + 1] = (I)u; T.ring[lo + 2] = (I)TT::REM;
+                I* ru = T.ring + T.loff[u];
+                const uint32_t du = T.llen[u];
+                for (uint32_t q = 0; q < du; ++q) if ((uint32_t)ru[q] == v) { ru[q] = (I)fresh; break; }
+                r[j] = (I)fresh;
+            }
         }
-        uint32_t hend = hcur + 3u * M;
+        uint32_t hend = T.hUsed + 3u * M;
         __syncthreads();
         STAMP(5);
 
@@ -593,33 +787,31 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
         {
             // regular cap: every new vertex X=[cut, kept] finds its successor by walking the face
             // loop through clipped vertices; its final ring is [pred, succ, kept].
-            uint32_t* succ = S.aux0; uint32_t* pred = S.aux1; uint32_t* pcnt = S.aux2;
-            for (uint32_t t = tid; t < M; t += SURTR_WG) pcnt[t] = 0;
+            for (uint32_t t = tid; t < M; t += SURTR_WG) T.pcnt[t] = 0;
             __syncthreads();
             bool bad = false;
             for (uint32_t t = tid; t < M; t += SURTR_WG)
             {
                 const uint32_t X = n0 + t;
-                int32_t prev = (int32_t)X, c = B.nbr[B.loff[X]];
-                uint32_t steps = 0;
-                while (c >= 0 && B.comp[c] == -1 && steps++ < n1)
+                uint32_t prev = X, c = T.ring[T.loff[X]], steps = 0;
+                while (c < TT::SENT && T.comp[c] == -1 && steps++ < n1)
                 {
-                    const int32_t hold = c;
-                    c = face_next(B.nbr + B.loff[c], B.llen[c], prev);
+                    const uint32_t hold = c;
+                    c = face_next(T.ring + T.loff[c], T.llen[c], prev);
                     prev = hold;
                 }
-                if (c < (int32_t)n0 || c == (int32_t)X || B.comp[c] != 2) { bad = true; succ[t] = X; }
+                if (c >= TT::SENT || c < n0 || c == X || T.comp[c] != 2) { bad = true; T.succ[t] = X; }
                 else
                 {
-                    succ[t] = (uint32_t)c;
-                    atomicAdd(&pcnt[(uint32_t)c - n0], 1u);
-                    pred[(uint32_t)c - n0] = X;
+                    T.succ[t] = c;
+                    atomicAdd(&T.pcnt[c - n0], 1u);
+                    T.pred[c - n0] = X;
                 }
             }
             if (bad) sh.flagBad = 1;
             __syncthreads();
             bad = false;
-            for (uint32_t t = tid; t < M; t += SURTR_WG) if (pcnt[t] != 1u) bad = true;
+            for (uint32_t t = tid; t < M; t += SURTR_WG) if (T.pcnt[t] != 1u) bad = true;
             if (bad) sh.flagBad = 1;
             __syncthreads();
             serial = sh.flagBad != 0;
@@ -627,25 +819,29 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
             {
                 for (uint32_t t = tid; t < M; t += SURTR_WG)
                 {
-                    const uint32_t lo = B.loff[n0 + t];
-                    const int32_t kept = B.nbr[lo + 1];
-                    B.nbr[lo] = (int32_t)pred[t]; B.nbr[lo + 1] = (int32_t)succ[t]; B.nbr[lo + 2] = kept;
-                    B.llen[n0 + t] = 3;
+                    const uint32_t lo = T.loff[n0 + t];
+                    const I kept = T.ring[lo + 1];
+                    T.ring[lo] = (I)T.pred[t]; T.ring[lo + 1] = (I)T.succ[t]; T.ring[lo + 2] = kept;
+                    T.llen[n0 + t] = 3;
                 }
             }
+            __syncthreads();
+            if (tid == 0) sh.flagBad = 0;
+            __syncthreads();
         }
         if (serial)
         {
             COUNT(19);
             // give every in-plane vertex a ring with room for insertions plus its snapshot
-            uint32_t* snapoff = S.aux0; uint32_t* cap = S.aux1; uint32_t* zlist = S.aux2;
+            uint32_t* snapoff = T.aux0; uint32_t* cap = T.aux1; uint32_t* zlist = T.aux2;
             auto zfn = [&](uint32_t v) -> uint2 {
-                return (B.comp[v] == 0) ? make_uint2(1u, 4u * B.llen[v]) : make_uint2(0u, 0u);
+                return (T.comp[v] == 0) ? make_uint2(1u, 4u * (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
             };
             uint32_t zc = 0, zw = 0;
-            scan_blocks(n0, S.blk, sh, zfn, zc, zw);
-            if (hend + zw > S.CH) return 3;
+            scan_blocks(n0, T.blk, sh, zfn, zc, zw);
+            if (hend + zw > T.capH) { COUNT(37); return SURTR_OVERFLOW; }
             const uint32_t nb = (n0 + SURTR_LANES - 1u) >> SURTR_LSH;
+            bool toolong = false;
             for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
             {
                 const uint32_t v = (b << SURTR_LSH) + l;
@@ -654,93 +850,118 @@ __device__ int clip_solid(const SolidIn in, const uint32_t F, Scratch& S, Shared
                 const uint2 e = wave_excl2(c);
                 if (v < n0 && c.x)
                 {
-                    const uint32_t len = B.llen[v];
-                    const uint32_t dst = hend + S.blk[b].y + e.y;
-                    const int32_t* src = B.nbr + B.loff[v];
-                    for (uint32_t q = 0; q < len; ++q) { B.nbr[dst + q] = src[q]; B.nbr[dst + 2u * len + q] = src[q]; }
-                    B.loff[v] = dst; snapoff[v] = dst + 2u * len; cap[v] = 2u * len;
-                    zlist[S.blk[b].x + e.x] = v;
+                    const uint32_t len = T.llen[v];
+                    const uint32_t dst = hend + T.blk[b].y + e.y;
+                    const I* src = T.ring + T.loff[v];
+                    for (uint32_t q = 0; q < len; ++q) { T.ring[dst + q] = src[q]; T.ring[dst + 2u * len + q] = src[q]; }
+                    T.loff[v] = (typename TT::off_t)dst; snapoff[v] = dst + 2u * len; cap[v] = 2u * len;
+                    zlist[T.blk[b].x + e.x] = v;
+                    if (2u * len > TT::MAXLEN) toolong = true;
                 }
             }
+            if (toolong) sh.flagBad = 1;
             hend += zw;
             __syncthreads();
-            if (tid == 0) relink_serial(B, n0, n1, snapoff, cap, zlist, zc, sh);
+            if (sh.flagBad) { COUNT(38); return SURTR_OVERFLOW; }     // a ring could outgrow this Topo's length type
+            if (tid == 0) relink_serial(T, n0, n1, snapoff, cap, zlist, zc, sh);
             __syncthreads();
             if (sh.flagErr) return 2;
-            // drop the -1 marks (:426-431), one vertex per lane; then look for two-neighbour vertices
+            // drop the REM marks (:426-431), one vertex per lane; then look for two-neighbour vertices
             if (tid == 0) sh.changed = 0;
             __syncthreads();
             {
                 bool two = false;
                 for (uint32_t v = tid; v < n1; v += SURTR_WG)
                 {
-                    int32_t* r = B.nbr + B.loff[v];
-                    const uint32_t len = B.llen[v];
+                    if (T.comp[v] == SURTR_DEAD) continue;
+                    I* r = T.ring + T.loff[v];
+                    const uint32_t len = T.llen[v];
                     uint32_t wq = 0;
-                    for (uint32_t q = 0; q < len; ++q) { const int32_t u = r[q]; if (u != -1) r[wq++] = u; }
-                    B.llen[v] = wq;
-                    if (B.comp[v] >= 0 && wq == 2u) two = true;
+                    for (uint32_t q = 0; q < len; ++q) { const I u = r[q]; if ((uint32_t)u != TT::REM) r[wq++] = u; }
+                    T.llen[v] = (typename TT::len_t)wq;
+                    if (T.comp[v] >= 0 && wq == 2u) two = true;
                 }
                 if (two) sh.changed = 1;
             }
             __syncthreads();
             if (sh.changed)
             {
-                if (tid == 0) collapse_serial(B, n1);
+                if (tid == 0) collapse_serial(T, n1);
                 __syncthreads();
             }
         }
-
         __syncthreads();     // rings and lengths of this plane are final
         STAMP(6);
-        // ---- compaction (:464-495) ----
-        Buf& D = S.b[cur ^ 1u];
-        auto livefn = [&](uint32_t v) -> uint2 {
-            return (B.comp[v] >= 0) ? make_uint2(1u, B.llen[v]) : make_uint2(0u, 0u);
-        };
-        uint32_t nn = 0, hh = 0;
-        scan_blocks(n1, S.blk, sh, livefn, nn, hh);
-        uint32_t* idmap = S.aux0;
+        // ---- tombstones instead of the per-plane compaction (:464-495); live count for :497-499 ----
+        if (tid == 0) sh.misc[1] = 0;
+        __syncthreads();
         {
-            const uint32_t nb = (n1 + SURTR_LANES - 1u) >> SURTR_LSH;
-            for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
+            uint32_t live = 0; bool dangling = false;
+            for (uint32_t v = tid; v < n1; v += SURTR_WG)
             {
-                const uint32_t v = (b << SURTR_LSH) + l;
-                uint2 c = make_uint2(0u, 0u);
-                if (v < n1) c = livefn(v);
-                const uint2 e = wave_excl2(c);
-                if (v < n1 && c.x)
+                const int c = T.comp[v];
+                if (c == SURTR_DEAD || c < 0) continue;
+                ++live;
+                const I* r = T.ring + T.loff[v];
+                const uint32_t len = T.llen[v];
+                for (uint32_t q = 0; q < len; ++q)
                 {
-                    const uint32_t id = S.blk[b].x + e.x;
-                    idmap[v] = id;
-                    D.pos[3 * id] = B.pos[3 * v]; D.pos[3 * id + 1] = B.pos[3 * v + 1]; D.pos[3 * id + 2] = B.pos[3 * v + 2];
-                    D.loff[id] = S.blk[b].y + e.y; D.llen[id] = c.y; D.comp[id] = B.comp[v];
+                    const uint32_t u = r[q];
+                    if (u < TT::SENT && T.comp[u] < 0) dangling = true;   // a live vertex still links a clipped one
                 }
             }
-        }
-        __syncthreads();
-        for (uint32_t v = tid; v < n1; v += SURTR_WG)
-        {
-            if (B.comp[v] < 0) continue;
-            const uint32_t id = idmap[v];
-            const int32_t* r = B.nbr + B.loff[v];
-            int32_t* d = D.nbr + D.loff[id];
-            const uint32_t len = B.llen[v];
-            for (uint32_t q = 0; q < len; ++q)
-            {
-                const int32_t u = r[q];
-                if (u >= 0 && B.comp[u] < 0) { SURTR_DBG("compaction: live %u links clipped %d (k=%u)\n", v, u, k); sh.flagErr = 1; d[q] = 0; continue; }
-                d[q] = u < 0 ? u : (int32_t)idmap[u];
-            }
+            if (dangling) { SURTR_DBG("plane %u: live vertex links a clipped one\n", k); sh.flagErr = 1; }
+            if (live) atomicAdd(&sh.misc[1], live);
         }
         __syncthreads();
         if (sh.flagErr) return 2;
+        for (uint32_t v = tid; v < n1; v += SURTR_WG) if (T.comp[v] < 0) T.comp[v] = SURTR_DEAD;
+        T.nS = n1; T.hUsed = hend; T.nLive = sh.misc[1];
+        __syncthreads();
         STAMP(7);
-        cur ^= 1u; n = nn; hcur = hh;
-        if (n + dropAlive < 4u) { n = 0; break; }
+        if (T.nLive + dropAlive < 4u) { T.nLive = 0; break; }
     }
-    *outN = n; *outBuf = cur; *outH = (n == 0) ? 0u : hcur;
     return 0;
+}
+
+// Assigns the final (compacted) index of every live slot: idmap = T.aux0, ring offset in the packed
+// ring array = T.aux2.  Returns (vertices, ring entries).
+template <class TT>
+__device__ uint2 index_live(Topo<TT>& T, Shared& sh)
+{
+    auto livefn = [&](uint32_t v) -> uint2 {
+        return (T.comp[v] != SURTR_DEAD) ? make_uint2(1u, (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
+    };
+    uint32_t nn = 0, hh = 0;
+    scan_blocks(T.nS, T.blk, sh, livefn, nn, hh);
+    const uint32_t nb = (T.nS + SURTR_LANES - 1u) >> SURTR_LSH;
+    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    {
+        const uint32_t v = (b << SURTR_LSH) + lane_id();
+        uint2 c = make_uint2(0u, 0u);
+        if (v < T.nS) c = livefn(v);
+        const uint2 e = wave_excl2(c);
+        if (v < T.nS && c.x) { T.aux0[v] = T.blk[b].x + e.x; T.aux2[v] = T.blk[b].y + e.y; }
+    }
+    __syncthreads();
+    return make_uint2(nn, hh);
+}
+
+// Writes the live part of T as a packed solid: positions, absolute ring offsets (hoff + ...), lengths, rings.
+template <class TT>
+__device__ void write_solid(const Topo<TT>& T, float* dpos, uint32_t* dloff, uint32_t* dllen, int32_t* dnbr, uint32_t voff,
+                            uint32_t hoff)
+{
+    for (uint32_t v = threadIdx.x; v < T.nS; v += SURTR_WG)
+    {
+        if (T.comp[v] == SURTR_DEAD) continue;
+        const uint32_t id = voff + T.aux0[v];
+        dpos[3 * (size_t)id] = T.pos[3 * v]; dpos[3 * (size_t)id + 1] = T.pos[3 * v + 1]; dpos[3 * (size_t)id + 2] = T.pos[3 * v + 2];
+        const uint32_t lo = hoff + T.aux2[v], len = T.llen[v];
+        dloff[id] = lo; dllen[id] = len;
+        const typename TT::idx_t* r = T.ring + T.loff[v];
+        for (uint32_t q = 0; q < len; ++q) dnbr[lo + q] = (int32_t)T.aux0[(uint32_t)r[q]];
+    }
 }
 
 } // namespace surtr

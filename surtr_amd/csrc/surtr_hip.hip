@@ -55,15 +55,29 @@ struct Arena
 
 struct Pieces
 {
-    const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri;
-    const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri;
+    const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri; const float* mrad;
+    const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri; const float* crad;
     uint32_t n;
 };
 
 struct ScratchPool
 {
     char* base; size_t per_wg;
-    uint32_t CV, CH, VMAX, NB;
+    uint32_t CV, CH, VMAX;
+};
+
+// Per-workgroup global scratch: positions of the reduced solid (both variants), the wide (32-bit)
+// topology used when a solid does not fit the LDS one, three u32 work arrays, scan blocks, pre-pass masks.
+struct Scratch
+{
+    float* pos;
+    uint32_t* g_loff; uint32_t* g_llen; int8_t* g_comp; uint32_t* g_ring;
+    uint32_t* g_succ; uint32_t* g_pred; uint32_t* g_pcnt;
+    uint32_t* aux0; uint32_t* aux1; uint32_t* aux2;
+    uint2* blk;
+    unsigned long long* gmask; uint2* gblk;
+    float* t_pos; uint32_t* t_loff; uint32_t* t_llen; int8_t* t_comp; uint32_t* t_ring;   // squeeze() staging
+    uint32_t CV, CH;
 };
 
 __device__ static Scratch carve(const ScratchPool& P, uint32_t wg)
@@ -71,30 +85,89 @@ __device__ static Scratch carve(const ScratchPool& P, uint32_t wg)
     Scratch S;
     char* p = P.base + (size_t)wg * P.per_wg;
     auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-    for (int i = 0; i < 2; ++i)
-    {
-        S.b[i].pos = (float*)take((size_t)P.CV * 12);
-        S.b[i].loff = (uint32_t*)take((size_t)P.CV * 4);
-        S.b[i].llen = (uint32_t*)take((size_t)P.CV * 4);
-        S.b[i].comp = (int8_t*)take((size_t)P.CV);
-        S.b[i].nbr = (int32_t*)take((size_t)P.CH * 4);
-    }
+    S.pos = (float*)take((size_t)P.CV * 12);
+    S.g_loff = (uint32_t*)take((size_t)P.CV * 4);
+    S.g_llen = (uint32_t*)take((size_t)P.CV * 4);
+    S.g_comp = (int8_t*)take((size_t)P.CV);
+    S.g_ring = (uint32_t*)take((size_t)P.CH * 4);
+    S.g_succ = (uint32_t*)take((size_t)P.CV * 4);
+    S.g_pred = (uint32_t*)take((size_t)P.CV * 4);
+    S.g_pcnt = (uint32_t*)take((size_t)P.CV * 4);
     S.aux0 = (uint32_t*)take((size_t)P.CV * 4);
     S.aux1 = (uint32_t*)take((size_t)P.CV * 4);
     S.aux2 = (uint32_t*)take((size_t)P.CV * 4);
+    S.blk = (uint2*)take((size_t)(P.CV / SURTR_LANES + 4) * 8);
     S.gmask = (unsigned long long*)take((size_t)(P.VMAX / SURTR_LANES + 2) * 8);
-    S.blk = (uint2*)take((size_t)P.NB * 8);
+    S.gblk = (uint2*)take((size_t)(P.VMAX / SURTR_LANES + 2) * 8);
+    S.t_pos = (float*)take((size_t)P.CV * 12); S.t_loff = (uint32_t*)take((size_t)P.CV * 4); S.t_llen = (uint32_t*)take((size_t)P.CV * 4);
+    S.t_comp = (int8_t*)take((size_t)P.CV); S.t_ring = (uint32_t*)take((size_t)P.CH * 4);
     S.CV = P.CV; S.CH = P.CH;
     return S;
 }
 
-static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX, uint32_t NB)
+static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX)
 {
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    size_t t = 0;
-    for (int i = 0; i < 2; ++i) t += r((size_t)CV * 12) + 2 * r((size_t)CV * 4) + r((size_t)CV) + r((size_t)CH * 4);
-    t += 3 * r((size_t)CV * 4) + r((size_t)(VMAX / SURTR_LANES + 2) * 8) + r((size_t)NB * 8);
-    return t;
+    return 2 * r((size_t)CV * 12) + 10 * r((size_t)CV * 4) + 2 * r((size_t)CV) + 2 * r((size_t)CH * 4) + r((size_t)(CV / SURTR_LANES + 4) * 8) +
+           2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
+}
+
+// LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
+struct LdsTopo
+{
+    uint16_t loff[SURTR_LV];
+    uint8_t llen[SURTR_LV];
+    int8_t comp[SURTR_LV];
+    uint2 blk[SURTR_LV / SURTR_LANES + 2];
+    unsigned long long align_;
+    uint16_t ring[SURTR_LH];
+};
+
+// Clips `in` by sh.planes[0..F) and hands the resulting Topo (nLive == 0: empty) to `consume`.
+// Returns 0 or an error code (uniform over the workgroup).
+template <class Consume>
+__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LdsTopo& L, Consume consume)
+{
+    const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
+    int rc;
+    {
+        Topo<InLds> T;
+        T.loff = L.loff; T.llen = L.llen; T.comp = L.comp; T.ring = L.ring; T.pos = S.pos;
+        T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = L.blk;
+        T.capV = SURTR_LV < S.CV ? SURTR_LV : S.CV; T.capH = SURTR_LH;
+        T.nS = T.nLive = T.hUsed = 0;
+        // pre-pass masks sit in the tail of the ring area while the reduced solid is being emitted
+        // (the tail is free again afterwards); a copy of the bit mask goes to global scratch for the
+        // all-in-plane corner case of clip_planes
+        unsigned long long* bmask = S.gmask; uint2* bblk = S.gblk; uint32_t capEmit = SURTR_LH;
+        if ((size_t)nbV * 8u <= SURTR_LH / 2u)
+        {
+            bblk = (uint2*)(L.ring + SURTR_LH) - nbV;
+            bmask = (unsigned long long*)bblk - nbV;
+            capEmit = SURTR_LH - nbV * 8u;
+        }
+        rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
+        if (rc == 0)
+        {
+            __syncthreads();
+            rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
+        }
+        __syncthreads();
+        if (rc == 0) return consume(T);
+    }
+    if (rc != SURTR_OVERFLOW) return rc;
+    COUNT(20);
+    Topo<InGlobal> T;
+    T.loff = S.g_loff; T.llen = S.g_llen; T.comp = S.g_comp; T.ring = S.g_ring; T.pos = S.pos;
+    T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = S.blk;
+    T.capV = S.CV; T.capH = S.CH;
+    T.nS = T.nLive = T.hUsed = 0;
+    rc = prepass(in, F, T, sh, S.gmask, S.gblk, S.CH, nullptr, nullptr);
+    if (rc == 0) { __syncthreads(); rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring}); }
+    __syncthreads();
+    if (rc == SURTR_OVERFLOW) return SURTR_E_CAPACITY;
+    if (rc != 0) return rc;
+    return consume(T);
 }
 
 // ------------------------------------------------------------- small helpers
@@ -133,23 +206,10 @@ __global__ void k_place_cells(uint32_t nfaces, const float* __restrict__ v012, f
 }
 
 // ------------------------------------------------------------- arena output
-// Copies a packed solid (rings in vertex order) from a scratch buffer to the arena.
-__device__ static void park_solid(const Buf& B, uint32_t n, uint32_t nh, const Arena& A, uint32_t voff, uint32_t hoff)
-{
-    for (uint32_t v = threadIdx.x; v < n; v += SURTR_WG)
-    {
-        A.pos[3 * (size_t)(voff + v)] = B.pos[3 * v];
-        A.pos[3 * (size_t)(voff + v) + 1] = B.pos[3 * v + 1];
-        A.pos[3 * (size_t)(voff + v) + 2] = B.pos[3 * v + 2];
-        A.loff[voff + v] = hoff + B.loff[v];
-        A.llen[voff + v] = B.llen[v];
-    }
-    for (uint32_t e = threadIdx.x; e < nh; e += SURTR_WG) A.nbr[hoff + e] = B.nbr[e];
-}
-
 __device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
                                   uint32_t& voff, uint32_t& hoff, uint32_t& ioff)
 {
+    __syncthreads();
     if (threadIdx.x == 0)
     {
         sh.misc[0] = atomicAdd(&A.cursors[0], nv);
@@ -163,6 +223,121 @@ __device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint3
     return ok;
 }
 
+// Writes the clipped solid (one piece of output) to the arena.  Returns 0 / SURTR_E_CAPACITY.
+template <class TT>
+__device__ static int park_topo(Topo<TT>& T, Shared& sh, const Arena& A, uint32_t& voff, uint32_t& n, uint32_t& hoff, uint32_t& nh)
+{
+    const uint2 tot = index_live(T, sh);
+    uint32_t ioff;
+    if (!arena_take(A, sh, tot.x, tot.y, 0, voff, hoff, ioff)) return SURTR_E_CAPACITY;
+    write_solid(T, A.pos, A.loff, A.llen, A.nbr, voff, hoff);
+    n = tot.x; nh = tot.y;
+    __syncthreads();
+    return 0;
+}
+
+// Islands of the clipped Mesh (CheckMeshIsland, Src/Surtr.cpp:2157-2201) + the island-major copy to the
+// arena (the re-indexing of m_fractureTask, :1474-1500).  Islands are numbered by their lowest vertex.
+template <class TT>
+__device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A, PairRec& rec)
+{
+    typedef typename TT::idx_t I;
+    const uint32_t tid = threadIdx.x, nS = T.nS;
+    const uint2 tot = index_live(T, sh);              // aux0 = packed index, aux2 = packed ring offset
+    uint32_t* lab = T.aux1;
+    for (uint32_t v = tid; v < nS; v += SURTR_WG) lab[v] = v;
+    __syncthreads();
+    while (true)
+    {
+        if (tid == 0) sh.changed = 0;
+        __syncthreads();
+        bool ch = false;
+        for (uint32_t v = tid; v < nS; v += SURTR_WG)
+        {
+            if (T.comp[v] == SURTR_DEAD) continue;
+            uint32_t m = lab[v];
+            const I* r = T.ring + T.loff[v];
+            const uint32_t len = T.llen[v];
+            for (uint32_t q = 0; q < len; ++q) { const uint32_t o = lab[(uint32_t)r[q]]; m = o < m ? o : m; }
+            const uint32_t mm = lab[m];
+            m = mm < m ? mm : m;
+            if (m < lab[v]) { lab[v] = m; ch = true; }
+        }
+        if (ch) sh.changed = 1;
+        __syncthreads();
+        const bool more = sh.changed != 0;
+        __syncthreads();     // read before lane 0 clears it again
+        if (!more) break;
+    }
+    auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2((T.comp[v] != SURTR_DEAD && lab[v] == v) ? 1u : 0u, 0u); };
+    uint32_t ni = 0, dum = 0;
+    scan_blocks(nS, T.blk, sh, rootfn, ni, dum);
+    uint32_t voff, hoff, ioff;
+    if (!arena_take(A, sh, tot.x, tot.y, ni, voff, hoff, ioff)) return SURTR_E_CAPACITY;
+    if (ni == 1)
+    {
+        write_solid(T, A.pos, A.loff, A.llen, A.nbr, voff, hoff);
+        if (tid == 0) A.isl[ioff] = tot;
+    }
+    else
+    {
+        // island index of a root = its rank among roots (discovery order = lowest vertex first)
+        uint32_t* irank = T.aux2; uint32_t* local = T.aux0;
+        const uint32_t nb = (nS + SURTR_LANES - 1u) >> SURTR_LSH;
+        for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+        {
+            const uint32_t v = (b << SURTR_LSH) + lane_id();
+            uint2 c = make_uint2(0u, 0u);
+            if (v < nS) c = rootfn(v);
+            const uint2 e = wave_excl2(c);
+            if (v < nS && c.x) irank[v] = T.blk[b].x + e.x;
+        }
+        __syncthreads();
+        uint32_t vbase = 0, hbase = 0;
+        for (uint32_t t = 0; t < ni; ++t)
+        {
+            auto isfn = [&](uint32_t v) -> uint2 {
+                return (T.comp[v] != SURTR_DEAD && irank[lab[v]] == t) ? make_uint2(1u, (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
+            };
+            uint32_t tv = 0, th = 0;
+            scan_blocks(nS, T.blk, sh, isfn, tv, th);
+            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            {
+                const uint32_t v = (b << SURTR_LSH) + lane_id();
+                uint2 c = make_uint2(0u, 0u);
+                if (v < nS) c = isfn(v);
+                const uint2 e = wave_excl2(c);
+                if (v < nS && c.x)
+                {
+                    const uint32_t lv = T.blk[b].x + e.x;
+                    const uint32_t dv = voff + vbase + lv;
+                    local[v] = lv;
+                    A.pos[3 * (size_t)dv] = T.pos[3 * v]; A.pos[3 * (size_t)dv + 1] = T.pos[3 * v + 1];
+                    A.pos[3 * (size_t)dv + 2] = T.pos[3 * v + 2];
+                    A.llen[dv] = c.y;
+                    A.loff[dv] = hoff + hbase + T.blk[b].y + e.y;
+                }
+            }
+            if (tid == 0) A.isl[ioff + t] = make_uint2(tv, th);
+            __syncthreads();
+            for (uint32_t v = tid; v < nS; v += SURTR_WG)
+            {
+                if (T.comp[v] == SURTR_DEAD || irank[lab[v]] != t) continue;
+                const uint32_t dv = voff + vbase + local[v];
+                const I* r = T.ring + T.loff[v];
+                int32_t* d = A.nbr + A.loff[dv];
+                const uint32_t len = T.llen[v];
+                for (uint32_t q = 0; q < len; ++q) d[q] = (int32_t)local[(uint32_t)r[q]];
+            }
+            vbase += tv; hbase += th;
+            __syncthreads();
+        }
+    }
+    rec.mv_off = voff; rec.mv_n = tot.x; rec.mh_off = hoff; rec.mh_n = tot.y; rec.ni = ni; rec.isl_off = ioff;
+    __syncthreads();
+    return 0;
+}
+
 // -------------------------------------------------------------- k_clip_pairs
 __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
@@ -170,21 +345,19 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
                                                          ScratchPool pool, Arena A, PairRec* __restrict__ pairs)
 {
     __shared__ Shared sh;
+    __shared__ LdsTopo L;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
-    STAMP_DECL;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
     while (true)
     {
         __syncthreads();
-        STAMP(15);
         if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[4], 1u);
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
-        STAMP(8);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
@@ -194,144 +367,36 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
         bool skip = outside != nullptr && outside[piece] != 0;
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
-        uint32_t cn = 0, cb = 0, chn = 0, mn = 0, mb = 0, mhn = 0;
         int err = 0;
         if (!skip)
         {
             for (uint32_t k = tid; k < F; k += SURTR_WG) sh.planes[k] = planes[f0 + k];
             __syncthreads();
-            // Convex first (Src/Surtr.cpp:1466-1468)
+            // Convex first (Src/Surtr.cpp:1466-1468); an empty Convex skips the Mesh
             const uint32_t c0 = P.cvo[piece];
-            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0};
-            STAMP(9);
-            err = clip_solid(cin, F, S, sh, &cn, &cb, &chn);
+            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0};
+            bool have_convex = false;
+            err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
+                if (T.nLive == 0) return 0;
+                have_convex = true;
+                return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
+            });
             __syncthreads();
-            STAMP(10);
-        }
-        if (!skip && err == 0 && cn > 0)
-        {
-            uint32_t voff, hoff, ioff;
-            if (!arena_take(A, sh, cn, chn, 0, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
-            else
-            {
-                park_solid(S.b[cb], cn, chn, A, voff, hoff);
-                rec.cv_off = voff; rec.cv_n = cn; rec.ch_off = hoff; rec.ch_n = chn;
-            }
-            __syncthreads();
-            if (err == 0)
+            if (err == 0 && have_convex)
             {
                 const uint32_t m0 = P.mvo[piece];
-                SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0};
-                STAMP(11);
-                err = clip_solid(min, F, S, sh, &mn, &mb, &mhn);
+                SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0};
+                err = clip_any(min, F, S, sh, L, [&](auto& T) -> int {
+                    if (T.nLive == 0) return 0;
+                    return park_mesh_islands(T, sh, A, rec);
+                });
                 __syncthreads();
-                STAMP(12);
-            }
-        }
-        if (!skip && err == 0 && cn > 0 && mn > 0)
-        {
-            // ---- islands: min-label propagation (CheckMeshIsland, Src/Surtr.cpp:2157-2201) ----
-            Buf& B = S.b[mb];
-            uint32_t* lab = S.aux0;
-            for (uint32_t v = tid; v < mn; v += SURTR_WG) lab[v] = v;
-            __syncthreads();
-            while (true)
-            {
-                if (tid == 0) sh.changed = 0;
-                __syncthreads();
-                bool ch = false;
-                for (uint32_t v = tid; v < mn; v += SURTR_WG)
-                {
-                    uint32_t m = lab[v];
-                    const int32_t* r = B.nbr + B.loff[v];
-                    const uint32_t len = B.llen[v];
-                    for (uint32_t q = 0; q < len; ++q) { const uint32_t o = lab[r[q]]; m = o < m ? o : m; }
-                    const uint32_t mm = lab[m];
-                    m = mm < m ? mm : m;
-                    if (m < lab[v]) { lab[v] = m; ch = true; }
-                }
-                if (ch) sh.changed = 1;
-                __syncthreads();
-                const bool more = sh.changed != 0;
-                __syncthreads();     // read before lane 0 clears it again
-                if (!more) break;
-            }
-            STAMP(13);
-            auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2(lab[v] == v ? 1u : 0u, 0u); };
-            uint32_t ni = 0, dum = 0;
-            scan_blocks(mn, S.blk, sh, rootfn, ni, dum);
-            uint32_t voff, hoff, ioff;
-            if (!arena_take(A, sh, mn, mhn, ni, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
-            else if (ni == 1)
-            {
-                park_solid(B, mn, mhn, A, voff, hoff);
-                if (tid == 0) A.isl[ioff] = make_uint2(mn, mhn);
-            }
-            else
-            {
-                // island index of every root = its rank among roots (discovery order = lowest vertex first)
-                uint32_t* irank = S.aux1; uint32_t* local = S.aux2;
-                const uint32_t nb = (mn + SURTR_LANES - 1u) >> SURTR_LSH;
-                for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
-                {
-                    const uint32_t v = (b << SURTR_LSH) + lane_id();
-                    uint2 c = make_uint2(0u, 0u);
-                    if (v < mn) c = rootfn(v);
-                    const uint2 e = wave_excl2(c);
-                    if (v < mn && c.x) irank[v] = S.blk[b].x + e.x;
-                }
-                __syncthreads();
-                uint32_t vbase = 0, hbase = 0;
-                for (uint32_t t = 0; t < ni; ++t)
-                {
-                    auto isfn = [&](uint32_t v) -> uint2 {
-                        return (irank[lab[v]] == t) ? make_uint2(1u, B.llen[v]) : make_uint2(0u, 0u);
-                    };
-                    uint32_t tv = 0, th = 0;
-                    scan_blocks(mn, S.blk, sh, isfn, tv, th);
-                    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
-                    {
-                        const uint32_t v = (b << SURTR_LSH) + lane_id();
-                        uint2 c = make_uint2(0u, 0u);
-                        if (v < mn) c = isfn(v);
-                        const uint2 e = wave_excl2(c);
-                        if (v < mn && c.x)
-                        {
-                            const uint32_t lv = S.blk[b].x + e.x;
-                            const uint32_t dv = voff + vbase + lv;
-                            local[v] = lv;
-                            A.pos[3 * (size_t)dv] = B.pos[3 * v]; A.pos[3 * (size_t)dv + 1] = B.pos[3 * v + 1];
-                            A.pos[3 * (size_t)dv + 2] = B.pos[3 * v + 2];
-                            A.llen[dv] = c.y;
-                            A.loff[dv] = hoff + hbase + S.blk[b].y + e.y;
-                        }
-                    }
-                    if (tid == 0) A.isl[ioff + t] = make_uint2(tv, th);
-                    __syncthreads();
-                    // rings of this island
-                    for (uint32_t v = tid; v < mn; v += SURTR_WG)
-                    {
-                        if (irank[lab[v]] != t) continue;
-                        const uint32_t dv = voff + vbase + local[v];
-                        const int32_t* r = B.nbr + B.loff[v];
-                        int32_t* d = A.nbr + A.loff[dv];
-                        const uint32_t len = B.llen[v];
-                        for (uint32_t q = 0; q < len; ++q) d[q] = (int32_t)local[r[q]];
-                    }
-                    vbase += tv; hbase += th;
-                    __syncthreads();
-                }
-            }
-            if (err == 0)
-            {
-                rec.mv_off = voff; rec.mv_n = mn; rec.mh_off = hoff; rec.mh_n = mhn; rec.ni = ni; rec.isl_off = ioff;
             }
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
-        STAMP(14);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 10 + 20) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 10) bkt = 10; atomicAdd(&g_stamp[21 + bkt], 1ull); }
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[21 + bkt], 1ull); }
 #endif
     }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -433,6 +498,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
     __shared__ float hp[4][3];
     __shared__ float nrm[4][3];
     __shared__ ArgF kmin[4][SURTR_NWAVE], kmax[4][SURTR_NWAVE];
+    __shared__ LdsTopo L;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
@@ -530,25 +596,18 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
             }
         }
         __syncthreads();
-        if (tid == 0) for (int k = 0; k < 8; ++k) SURTR_DBG("refit f=%u plane %d: %.9g %.9g %.9g %.9g\n", f, k, sh.planes[k].x, sh.planes[k].y, sh.planes[k].z, sh.planes[k].w);
-        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr};
-        // arena rings are absolute; make them relative by handing the absolute base (loff indexes A.nbr directly)
-        uint32_t cn = 0, cb = 0, chn = 0;
-        int err = clip_solid(cin, 8, S, sh, &cn, &cb, &chn);
+        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr};
+        // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
+        uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
+        int err = clip_any(cin, 8, S, sh, L, [&](auto& T) -> int {
+            if (T.nLive == 0) return 0;
+            return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
+        });
         __syncthreads();
-        if (err == 0)
+        if (err == 0 && tid == 0)
         {
-            uint32_t voff = 0, hoff = 0, ioff = 0;
-            if (cn > 0 && !arena_take(A, sh, cn, chn, 0, voff, hoff, ioff)) err = SURTR_E_CAPACITY;
-            else
-            {
-                if (cn > 0) park_solid(S.b[cb], cn, chn, A, voff, hoff);
-                if (tid == 0)
-                {
-                    fr.cv_off = voff; fr.cv_n = cn; fr.ch_off = hoff; fr.ch_n = chn;
-                    frags[f] = fr;
-                }
-            }
+            fr.cv_off = nvoff; fr.cv_n = ncn; fr.ch_off = nhoff; fr.ch_n = nchn;
+            frags[f] = fr;
         }
         if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
         (void)kmin; (void)kmax; (void)hp;
@@ -981,35 +1040,32 @@ __global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ f
 // ------------------------------------------------------------ single clip op
 __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const float4* __restrict__ planes, uint32_t F,
                                                           ScratchPool pool, float* opos, uint32_t* ooff, int32_t* onbr,
-                                                          uint32_t cap_v, uint32_t cap_h, uint32_t* result /* n, nh, status */)
+                                                          uint32_t* ollen, uint32_t cap_v, uint32_t cap_h,
+                                                          uint32_t* result /* n, nh, status */)
 {
     __shared__ Shared sh;
+    __shared__ LdsTopo L;
     Scratch S = carve(pool, 0);
     for (uint32_t k = threadIdx.x; k < F; k += SURTR_WG) sh.planes[k] = planes[k];
     __syncthreads();
-    uint32_t n = 0, b = 0, nh = 0;
-    int err = clip_solid(in, F, S, sh, &n, &b, &nh);
+    uint32_t n = 0, nh = 0;
+    int err = clip_any(in, F, S, sh, L, [&](auto& T) -> int {
+        if (T.nLive == 0) return 0;
+        const uint2 tot = index_live(T, sh);
+        if (tot.x > cap_v || tot.y > cap_h) return SURTR_E_CAPACITY;
+        write_solid(T, opos, ooff, ollen, onbr, 0, 0);
+        n = tot.x; nh = tot.y;
+        return 0;
+    });
     __syncthreads();
-    if (err == 0 && (n > cap_v || nh > cap_h)) err = SURTR_E_CAPACITY;
-    if (err == 0)
-    {
-        const Buf& B = S.b[b];
-        for (uint32_t v = threadIdx.x; v < n; v += SURTR_WG)
-        {
-            opos[3 * v] = B.pos[3 * v]; opos[3 * v + 1] = B.pos[3 * v + 1]; opos[3 * v + 2] = B.pos[3 * v + 2];
-            ooff[v] = B.loff[v];
-        }
-        for (uint32_t e = threadIdx.x; e < nh; e += SURTR_WG) onbr[e] = B.nbr[e];
-        if (threadIdx.x == 0) ooff[n] = nh;
-    }
-    if (threadIdx.x == 0) { result[0] = n; result[1] = nh; result[2] = (uint32_t)err; }
+    if (threadIdx.x == 0) { if (err == 0) ooff[n] = nh; result[0] = n; result[1] = nh; result[2] = (uint32_t)err; }
 }
 
 // =================================================================== host ===
 struct surtr_ctx
 {
     int device = 0;
-    uint32_t max_wg = 1024;
+    uint32_t max_wg = 512, max_wg_faces = 1024;
     hipStream_t stream = nullptr;
     std::string err;
     // pieces
@@ -1018,6 +1074,7 @@ struct surtr_ctx
     uint32_t *d_mloff = nullptr, *d_mllen = nullptr, *d_mvo = nullptr, *d_cloff = nullptr, *d_cllen = nullptr, *d_cvo = nullptr;
     int32_t *d_mnbr = nullptr, *d_cnbr = nullptr;
     uint8_t *d_mtri = nullptr, *d_ctri = nullptr;
+    float *d_mrad = nullptr, *d_crad = nullptr;
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
     uint32_t n_cells = 0, n_faces = 0;
@@ -1094,9 +1151,10 @@ int surtr_create(int device, surtr_ctx** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         {
-            uint32_t per_cu = SURTR_WG >= 256 ? 4u : (SURTR_WG >= 128 ? 8u : 16u);
+            uint32_t per_cu = 2u;      // k_clip_pairs / k_refit: LDS (one LdsTopo per workgroup) admits two per CU
             if (const char* e = getenv("SURTR_WG_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = (uint32_t)v; }
             ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
+            ctx->max_wg_faces = (uint32_t)prop.multiProcessorCount * 4u;
         }
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
@@ -1112,7 +1170,7 @@ void surtr_destroy(surtr_ctx* ctx)
     (void)hipDeviceSynchronize();
     free_dev(ctx->d_mpos); free_dev(ctx->d_cpos); free_dev(ctx->d_mloff); free_dev(ctx->d_mllen); free_dev(ctx->d_mvo);
     free_dev(ctx->d_cloff); free_dev(ctx->d_cllen); free_dev(ctx->d_cvo); free_dev(ctx->d_mnbr); free_dev(ctx->d_cnbr);
-    free_dev(ctx->d_mtri); free_dev(ctx->d_ctri);
+    free_dev(ctx->d_mtri); free_dev(ctx->d_ctri); free_dev(ctx->d_mrad); free_dev(ctx->d_crad);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
@@ -1168,7 +1226,7 @@ static int check_solid(uint32_t nv, const uint32_t* off, const int32_t* nbr)
 }
 
 static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const float* pos, const uint32_t* off, const int32_t* nbr,
-                      float** d_pos, uint32_t** d_loff, uint32_t** d_llen, int32_t** d_nbr, uint32_t** d_vo, uint8_t** d_tri,
+                      float** d_pos, uint32_t** d_loff, uint32_t** d_llen, int32_t** d_nbr, uint32_t** d_vo, uint8_t** d_tri, float** d_rad,
                       uint32_t& vmax, uint32_t& hmax, uint64_t& totv, uint64_t& toth)
 {
     const uint32_t V = vo[n];
@@ -1177,7 +1235,7 @@ static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const floa
     for (uint32_t p = 0; p < n; ++p)
     {
         const uint32_t a = vo[p], b = vo[p + 1];
-        if (b < a || b - a < 4) return SURTR_E_INVALID;
+        if (b < a || b - a < 4 || b - a >= (1u << 24)) return SURTR_E_INVALID;     // the pre-pass packs (vertex, plane) in 32 bits
         // local CSR view of this solid
         std::vector<uint32_t> loc(b - a + 1);
         for (uint32_t v = a; v <= b; ++v) loc[v - a] = off[v] - off[a];
@@ -1211,7 +1269,46 @@ static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const floa
             }
         }
     }
-    free_dev(*d_pos); free_dev(*d_tri); *d_tri = nullptr; free_dev(*d_loff); free_dev(*d_llen); free_dev(*d_nbr); free_dev(*d_vo);
+    // rad[v] = radius of a ball around v that holds every vertex of every face incident to v
+    std::vector<float> rad(V, 0.f);
+    for (uint32_t p = 0; p < n; ++p)
+    {
+        const uint32_t a = vo[p], b = vo[p + 1];
+        auto ringp = [&](int32_t lv) { return nbr + off[a + lv]; };
+        auto rlenp = [&](int32_t lv) { return off[a + lv + 1] - off[a + lv]; };
+        auto prevof2 = [&](int32_t lv, int32_t who) {
+            const int32_t* r = ringp(lv); const uint32_t len = rlenp(lv);
+            uint32_t k = 0;
+            while (k < len && r[k] != who) ++k;
+            return k == 0 ? r[len - 1] : r[k - 1];
+        };
+        auto dist = [&](uint32_t x, uint32_t y) {
+            const double dx = (double)pos[3 * (size_t)x] - pos[3 * (size_t)y], dy = (double)pos[3 * (size_t)x + 1] - pos[3 * (size_t)y + 1],
+                         dz = (double)pos[3 * (size_t)x + 2] - pos[3 * (size_t)y + 2];
+            return std::sqrt(dx * dx + dy * dy + dz * dz);
+        };
+        for (uint32_t v = a; v < b; ++v)
+        {
+            double r = 0.0;
+            const int32_t lv = (int32_t)(v - a);
+            for (uint32_t j = off[v]; j < off[v + 1]; ++j)
+            {
+                r = std::max(r, dist(v, a + nbr[j]));
+                if (!tri[v])
+                {
+                    int32_t prev = lv, cur = nbr[j]; uint32_t steps = 0;
+                    while (cur != lv && steps++ < b - a)
+                    {
+                        r = std::max(r, dist(v, a + cur));
+                        const int32_t nx = prevof2(cur, prev);
+                        prev = cur; cur = nx;
+                    }
+                }
+            }
+            rad[v] = (float)(r * 1.000001) + 1e-30f;
+        }
+    }
+    free_dev(*d_pos); free_dev(*d_tri); *d_tri = nullptr; free_dev(*d_rad); *d_rad = nullptr; free_dev(*d_loff); free_dev(*d_llen); free_dev(*d_nbr); free_dev(*d_vo);
     *d_pos = nullptr; *d_loff = nullptr; *d_llen = nullptr; *d_nbr = nullptr; *d_vo = nullptr;
     HIPCHK(hipMalloc((void**)d_pos, std::max<size_t>(16, (size_t)V * 12)));
     HIPCHK(hipMalloc((void**)d_loff, std::max<size_t>(16, (size_t)(V + 1) * 4)));
@@ -1225,6 +1322,8 @@ static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const floa
     HIPCHK(hipMemcpy(*d_vo, vo, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)d_tri, std::max<size_t>(16, (size_t)V)));
     HIPCHK(hipMemcpy(*d_tri, tri.data(), (size_t)V, hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)d_rad, std::max<size_t>(16, (size_t)V * 4)));
+    HIPCHK(hipMemcpy(*d_rad, rad.data(), (size_t)V * 4, hipMemcpyHostToDevice));
     totv = V; toth = H;
     return SURTR_OK;
 }
@@ -1235,10 +1334,10 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const f
     if (!ctx || n == 0 || !mvo || !mpos || !moff || !mnbr || !cvo || !cpos || !coff || !cnbr) return SURTR_E_INVALID;
     (void)hipSetDevice(ctx->device);
     uint32_t vmax = 0, hmax = 0; uint64_t tv = 0, th = 0, cv = 0, chh = 0;
-    int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri,
+    int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri, &ctx->d_mrad,
                         vmax, hmax, tv, th);
     if (rc) return rc;
-    rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri,
+    rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri, &ctx->d_crad,
                     vmax, hmax, cv, chh);
     if (rc) return rc;
     ctx->n_pieces = n; ctx->vmax = vmax; ctx->hmax = hmax; ctx->tot_mv = tv; ctx->tot_mh = th;
@@ -1302,22 +1401,25 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
 
 static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint32_t n_wg)
 {
-    uint32_t CV = ctx->user_cv ? ctx->user_cv : need_v + need_v / 2 + 1024;
-    uint32_t CH = ctx->user_ch ? ctx->user_ch : 2 * need_h + 8192;
+    const uint32_t n_wg_faces = std::max(n_wg, ctx->max_wg_faces);
+    // Tombstones keep every vertex ever created in its slot, so the wide (global) variant is sized for
+    // the band plus all cuts; the LDS variant has fixed capacities (SURTR_LV / SURTR_LH).
+    uint32_t CV = ctx->user_cv ? ctx->user_cv : 2 * need_v + 4096;
+    uint32_t CH = ctx->user_ch ? ctx->user_ch : 3 * need_h + 16384;
+    if (CV < 64) CV = 64;
     const uint32_t VMAX = need_v;
-    const uint32_t NB = (std::max(CV, VMAX) + SURTR_LANES - 1) / SURTR_LANES + 4;
     if (ctx->pool.base && ctx->pool.CV >= CV && ctx->pool.CH >= CH && ctx->pool.VMAX >= VMAX && ctx->n_wg >= n_wg) return SURTR_OK;
     free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     ctx->pool.base = nullptr; ctx->fs.base = nullptr; ctx->d_blk = nullptr;
-    ctx->pool.CV = CV; ctx->pool.CH = CH; ctx->pool.VMAX = VMAX; ctx->pool.NB = NB;
-    ctx->pool.per_wg = scratch_bytes_per_wg(CV, CH, VMAX, NB);
+    ctx->pool.CV = CV; ctx->pool.CH = CH; ctx->pool.VMAX = VMAX;
+    ctx->pool.per_wg = scratch_bytes_per_wg(CV, CH, VMAX);
     ctx->n_wg = n_wg;
     HIPCHK(hipMalloc((void**)&ctx->pool.base, ctx->pool.per_wg * n_wg));
-    ctx->fs.HF = CH / 2;
+    ctx->fs.HF = need_h + need_h / 2 + 8192;
     ctx->fs.per_wg = (size_t)12 * ctx->fs.HF;
-    HIPCHK(hipMalloc((void**)&ctx->fs.base, ctx->fs.per_wg * 4 * n_wg));
+    HIPCHK(hipMalloc((void**)&ctx->fs.base, ctx->fs.per_wg * 4 * n_wg_faces));
     ctx->blk_per_wg = ctx->fs.HF / SURTR_LANES + 4;
-    HIPCHK(hipMalloc((void**)&ctx->d_blk, (size_t)ctx->blk_per_wg * 8 * n_wg));
+    HIPCHK(hipMalloc((void**)&ctx->d_blk, (size_t)ctx->blk_per_wg * 8 * n_wg_faces));
     return SURTR_OK;
 }
 
@@ -1383,8 +1485,8 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
         HIPCHK(hipMemcpyAsync(ctx->d_outside, outside, ctx->n_pieces, hipMemcpyHostToDevice, st));
         d_out = ctx->d_outside;
     }
-    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri,
-             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->n_pieces};
+    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad,
+             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->n_pieces};
     for (int i = 0; i < 8; ++i) ctx->ev_valid[i] = false;
     PROF_BEGIN(0);
     if (n_pairs)
@@ -1404,7 +1506,7 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
     if (flags & SURTR_EVT_RENDER)
     {
         PROF_BEGIN(3);
-        hipLaunchKernelGGL(k_faces, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
+        hipLaunchKernelGGL(k_faces, dim3(std::max(n_wg, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
                            ctx->blk_per_wg, ctx->arena);
         PROF_END(3);
     }
@@ -1461,10 +1563,10 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
 }
 
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-int surtr_debug_stamps(unsigned long long out[32], int reset)
+int surtr_debug_stamps(unsigned long long out[48], int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32) != hipSuccess) return SURTR_E_HIP;
-    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 48) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[48] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
     return SURTR_OK;
 }
 #endif
@@ -1553,26 +1655,26 @@ int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const u
     rc = ensure_scratch(ctx, std::max(nv, ctx->vmax), std::max(H, ctx->hmax), std::max(1u, ctx->n_wg));
     if (rc) return rc;
     const uint32_t capv = ctx->pool.CV, caph = ctx->pool.CH;
-    float *d_pos = nullptr, *d_opos = nullptr; uint32_t *d_loff = nullptr, *d_llen = nullptr, *d_ooff = nullptr, *d_res = nullptr;
+    float *d_pos = nullptr, *d_opos = nullptr; uint32_t *d_loff = nullptr, *d_llen = nullptr, *d_ooff = nullptr, *d_res = nullptr, *d_ollen = nullptr;
     int32_t *d_nbr = nullptr, *d_onbr = nullptr; float4* d_pl = nullptr;
     std::vector<uint32_t> llen(nv);
     for (uint32_t v = 0; v < nv; ++v) llen[v] = off[v + 1] - off[v];
     auto cleanup = [&]() { free_dev(d_pos); free_dev(d_opos); free_dev(d_loff); free_dev(d_llen); free_dev(d_ooff); free_dev(d_res);
-                           free_dev(d_nbr); free_dev(d_onbr); free_dev(d_pl); };
+                           free_dev(d_nbr); free_dev(d_onbr); free_dev(d_pl); free_dev(d_ollen); };
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { ctx->err = hipGetErrorString(e_); cleanup(); return SURTR_E_HIP; } } while (0)
     CK(hipMalloc((void**)&d_pos, (size_t)nv * 12)); CK(hipMalloc((void**)&d_loff, (size_t)(nv + 1) * 4));
     CK(hipMalloc((void**)&d_llen, (size_t)nv * 4)); CK(hipMalloc((void**)&d_nbr, std::max<size_t>(16, (size_t)H * 4)));
     CK(hipMalloc((void**)&d_pl, std::max<size_t>(16, (size_t)n_planes * 16)));
     CK(hipMalloc((void**)&d_opos, (size_t)capv * 12)); CK(hipMalloc((void**)&d_ooff, (size_t)(capv + 1) * 4));
-    CK(hipMalloc((void**)&d_onbr, (size_t)caph * 4)); CK(hipMalloc((void**)&d_res, 16));
+    CK(hipMalloc((void**)&d_onbr, (size_t)caph * 4)); CK(hipMalloc((void**)&d_res, 16)); CK(hipMalloc((void**)&d_ollen, (size_t)(capv + 1) * 4));
     CK(hipMemcpy(d_pos, pos, (size_t)nv * 12, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_loff, off, (size_t)(nv + 1) * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_llen, llen.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
     if (n_planes) CK(hipMemcpy(d_pl, planes, (size_t)n_planes * 16, hipMemcpyHostToDevice));
-    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr};
+    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr, nullptr};
     hipLaunchKernelGGL(k_clip_single, dim3(1), dim3(SURTR_WG), 0, ctx->stream, in, d_pl, n_planes, ctx->pool, d_opos, d_ooff, d_onbr,
-                       capv, caph, d_res);
+                       d_ollen, capv, caph, d_res);
     CK(hipGetLastError());
     uint32_t res[3] = {0, 0, 0};
     CK(hipMemcpyAsync(res, d_res, 12, hipMemcpyDeviceToHost, ctx->stream));

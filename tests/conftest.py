@@ -24,8 +24,19 @@ def oracle():
 def emul_lib_path():
     """Single-lane CPU emulation of the kernels (tests/emul), built on demand."""
     d = os.path.join(ROOT, "tests", "emul")
-    subprocess.check_call(["make", "-s", "-C", d])
+    subprocess.check_call(["make", "-s", "-C", d, "all"])
     return os.path.join(d, "libsurtr_emul.so")
+
+
+@pytest.fixture()
+def emul_engine_small(emul_lib_path):
+    """Emulation built with a tiny LDS topology so that solids overflow into the wide (global) variant."""
+    from surtr_amd import engine
+    engine._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), "libsurtr_emul_small.so"))
+    try:
+        yield engine
+    finally:
+        engine._use_library_for_tests(None)
 
 
 @pytest.fixture()

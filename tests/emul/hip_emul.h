@@ -59,3 +59,4 @@ static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
         for (uint32_t bi_ = 0; bi_ < g_.x; ++bi_)                                          \
             for (uint32_t ti_ = 0; ti_ < b_.x; ++ti_) { blockIdx.x = bi_; threadIdx.x = ti_; kern(__VA_ARGS__); } \
     } while (0)
+template <class T> static inline T __shfl(T v, int, int) { return v; }

@@ -161,3 +161,19 @@ def test_in_plane_vertices_with_band_reduction(emul_engine, oracle):
         assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]), planes
         assert np.array_equal(a["pos"], b["pos"]), planes
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["cube", "blob", "islands"])
+def test_wide_global_variant(emul_engine_small, oracle, which):
+    """Same kernels, LDS capacities shrunk so the 32-bit global-scratch Topo is exercised."""
+    if which == "cube":
+        sc, cells = scenes.cube_scene(8), None
+    elif which == "blob":
+        sc, cells = scenes.blob_scene(64), None
+    else:
+        from surtr_amd import meshgen
+        v, t = meshgen.cube(1.0)
+        sc, cells = scenes.make_scene(np.concatenate([v, v + np.float32([5, 0, 0])]), np.concatenate([t, t + 8]), 6), None
+    c, got, ref = run_event(emul_engine_small, oracle, sc, 3, cells=cells)
+    assert_event_equal(got, ref)
+    assert np.array_equal(got["mesh_pos"], ref["mesh_pos"])

