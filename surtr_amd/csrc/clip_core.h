@@ -61,7 +61,7 @@ __device__ unsigned long long g_stamp[48];
 #define STAMP(i) do { } while (0)
 #endif
 
-#define SURTR_MAXF 255
+#define SURTR_MAXF 127          // planes per cell (Voronoi cells have ~15, an ACH k-DOP up to 72)
 #define SURTR_DEAD (-3)          // comp of a tombstone
 #define SURTR_OVERFLOW 100       // internal: the solid does not fit this Topo, redo with the larger one
 
@@ -121,6 +121,7 @@ struct Topo
 struct Shared
 {
     float4 planes[SURTR_MAXF + 1];
+    float4 pmar[SURTR_MAXF + 1];      // per plane: ball-test margin = rad*x + y + z*(|px|+|py|+|pz|)
     uint32_t hist[SURTR_MAXF + 1];    // after the pre-pass: dropped vertices still alive after plane k
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t wsum[2 * SURTR_NWAVE];
@@ -151,7 +152,9 @@ __device__ __forceinline__ float plane_dist(const float4 pl, float x, float y, f
 // ComparePlanePoint, Src/Poly.cpp:716-723.
 __device__ __forceinline__ int side_of(float s)
 {
-    if (fabs((double)s) < 1.0e-10) return 0;
+    // The reference compares std::abs(float) with the double literal 1.0e-10.  (float)1e-10 = 0x2EDBE6FF is
+    // >= 1e-10 and its predecessor is < 1e-10, so for every float x: (double)|x| < 1e-10  <=>  |x| < 1.0e-10f.
+    if (fabsf(s) < 1.0e-10f) return 0;
     float m = -s;
     return m > 0.f ? 1 : (m < 0.f ? -1 : 0);
 }
@@ -347,7 +350,17 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
     STAMP_DECL;
-    for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG) { sh.hist[k] = 0; sh.zhist[k] = 0; }
+    for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG)
+    {
+        sh.hist[k] = 0; sh.zhist[k] = 0;
+        if (k < F)
+        {
+            // conservative: nl >= |n|; the second and third terms bound the float rounding of n.p + d for v and its neighbours
+            const float4 pk = sh.planes[k];
+            const float nl = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);
+            sh.pmar[k] = make_float4(nl * 1.00101f, 1.0e-5f * fabsf(pk.w), 1.0e-5f * nl, 0.f);
+        }
+    }
     if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; sh.misc[3] = 0; }
     __syncthreads();
     const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
@@ -357,46 +370,71 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
-    for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
+    for (uint32_t b0 = w; b0 < nbV; b0 += 4u * SURTR_NWAVE)
     {
-        const uint32_t v = (b << SURTR_LSH) + l;
-        bool keep = false, need = false, drop = false; uint32_t f = 0xFFu;
-        if (v < V)
+        // four 64-blocks per wave iteration: their loads are in flight together, and every plane fetched
+        // from LDS is applied to all four (planes outermost: one LDS fetch per plane, four independent chains)
+        float px4[4], py4[4], pz4[4], rv4[4], mag4[4];
+        uint32_t f4[4]; bool done4[4], clear4[4], valid4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
         {
-            const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
-            const float rv = (in.rad != nullptr && V < (1u << 24)) ? in.rad[v] : -1.f;
-            const float mag = fabsf(px) + fabsf(py) + fabsf(pz);
-            bool ballClear = rv >= 0.f;
-            for (uint32_t k = 0; k < F; ++k)
-            {
-                const float4 pk = sh.planes[k];
-                const float sk = plane_dist(pk, px, py, pz);
-                const int c = side_of(sk);
-                if (ballClear)
-                {
-                    const float nl = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);            // >= |n|
-                    const float margin = rv * nl * 1.001f + 1.0e-5f * (fabsf(pk.w) + nl * (mag + rv));
-                    if (!(fabsf(sk) > margin)) ballClear = false;
-                }
-                if (c < 0) { f = k; break; }
-            }
-            keep = f == 0xFFu;
-            drop = !keep && ballClear;      // cannot be in-plane anywhere before fc (|s| > margin there)
-            need = !keep && !ballClear;
+            const uint32_t v = ((b0 + g * SURTR_NWAVE) << SURTR_LSH) + l;
+            valid4[g] = v < V;
+            const uint32_t vv = valid4[g] ? v : 0u;
+            px4[g] = in.pos[3 * vv]; py4[g] = in.pos[3 * vv + 1]; pz4[g] = in.pos[3 * vv + 2];
+            rv4[g] = (in.rad != nullptr && V < (1u << 24)) ? in.rad[vv] : -1.f;
         }
-        wave_hist_add(sh.hist, f, drop);
-#ifdef SURTR_EMUL
-        const unsigned long long mk = keep ? 1ull : 0ull, mn = need ? 1ull : 0ull;
-#else
-        const unsigned long long mk = __ballot(keep), mn = __ballot(need);
-#endif
-        if (l == 0) bmask[b] = mk;
-        if (mn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
         {
-            uint32_t base = 0;
-            if (l == 0) base = atomicAdd(&sh.misc[3], (uint32_t)__builtin_popcountll(mn));
-            base = (uint32_t)__shfl((int)base, 0, SURTR_LANES);
-            if (need) needy[base + (uint32_t)__builtin_popcountll(mn & ((1ull << l) - 1ull))] = v | (f << 24);
+            mag4[g] = fabsf(px4[g]) + fabsf(py4[g]) + fabsf(pz4[g]);
+            f4[g] = 0xFFu; done4[g] = !valid4[g]; clear4[g] = rv4[g] >= 0.f;
+        }
+        for (uint32_t k = 0; k < F; ++k)
+        {
+            const bool all_done = done4[0] && done4[1] && done4[2] && done4[3];
+#ifndef SURTR_EMUL
+            if (__all(all_done)) break;
+#else
+            if (all_done) break;
+#endif
+            const float4 pk = sh.planes[k];
+            const float4 mk = sh.pmar[k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+            {
+                if (done4[g]) continue;
+                const float sk = plane_dist(pk, px4[g], py4[g], pz4[g]);
+                const int c = side_of(sk);
+                if (clear4[g] && !(fabsf(sk) > rv4[g] * mk.x + mk.y + mk.z * mag4[g])) clear4[g] = false;
+                if (c < 0) { f4[g] = k; done4[g] = true; }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+        {
+            const uint32_t b = b0 + g * SURTR_NWAVE;
+            if (b >= nbV) break;
+            const uint32_t v = (b << SURTR_LSH) + l;
+            const uint32_t f = f4[g];
+            const bool keep = valid4[g] && f == 0xFFu;
+            const bool drop = valid4[g] && !keep && clear4[g];     // cannot be in-plane anywhere before fc (|s| > margin there)
+            const bool need = valid4[g] && !keep && !clear4[g];
+            wave_hist_add(sh.hist, f, drop);
+#ifdef SURTR_EMUL
+            const unsigned long long mk = keep ? 1ull : 0ull, mn = need ? 1ull : 0ull;
+#else
+            const unsigned long long mk = __ballot(keep), mn = __ballot(need);
+#endif
+            if (l == 0) bmask[b] = mk;
+            if (mn)
+            {
+                uint32_t base = 0;
+                if (l == 0) base = atomicAdd(&sh.misc[3], (uint32_t)__builtin_popcountll(mn));
+                base = (uint32_t)__shfl((int)base, 0, SURTR_LANES);
+                if (need) needy[base + (uint32_t)__builtin_popcountll(mn & ((1ull << l) - 1ull))] = v | (f << 24);
+            }
         }
     }
     __syncthreads();
@@ -707,12 +745,16 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         }
 
         // ---- new vertices on straddling edges, in (vertex, slot) order (:333-357) ----
+        uint32_t* cutcnt = T.aux2;     // per slot: kept neighbours of a clipped vertex (0 otherwise), written by the scan sweep
         auto cutfn = [&](uint32_t v) -> uint2 {
-            if (T.comp[v] != -1) return make_uint2(0u, 0u);
-            const I* r = T.ring + T.loff[v];
-            const uint32_t deg = T.llen[v];
             uint32_t c = 0;
-            for (uint32_t j = 0; j < deg; ++j) { const uint32_t u = r[j]; if (u < TT::SENT && T.comp[u] > 0) ++c; }
+            if (T.comp[v] == -1)
+            {
+                const I* r = T.ring + T.loff[v];
+                const uint32_t deg = T.llen[v];
+                for (uint32_t j = 0; j < deg; ++j) { const uint32_t u = r[j]; if (u < TT::SENT && T.comp[u] > 0) ++c; }
+                cutcnt[v] = c;         // only clipped vertices are written and read back (scratch traffic)
+            }
             return make_uint2(c, 1u);
         };
         uint32_t M = 0, nCut = 0;
@@ -736,7 +778,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             {
                 const uint32_t v = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
-                if (v < n0) c = cutfn(v);
+                if (v < n0 && T.comp[v] == -1) c.x = cutcnt[v];
                 const uint2 e = wave_excl2(c);
                 if (v < n0 && c.x)
                 {
@@ -902,6 +944,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 const int c = T.comp[v];
                 if (c == SURTR_DEAD || c < 0) continue;
                 ++live;
+                if (!serial) continue;       // a regular plane cannot leave such links (every one was replaced by a new vertex)
                 const I* r = T.ring + T.loff[v];
                 const uint32_t len = T.llen[v];
                 for (uint32_t q = 0; q < len; ++q)
