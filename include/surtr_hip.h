@@ -136,6 +136,16 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
                                const uint8_t* outside, uint32_t flags);
 int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts);
 
+/* Recursive refracture (BASELINE configs[4]): an explicit list of (cell, piece) pairs, processed and output in
+ * list order (e.g. fragment-major: every first-level fragment with its own cells).  Same pipeline and result
+ * layout as surtr_fracture_event; frag_ids carry the listed cell / piece numbers. */
+int surtr_fracture_pairs_async(surtr_ctx* ctx, uint32_t n_pairs, const uint32_t* pair_cell, const uint32_t* pair_piece,
+                               uint32_t flags);
+/* surtr_place_cells with one (scale, translate) per group of consecutive cells: group g owns cells
+ * [group_cell_off[g], group_cell_off[g+1]); scale3 / translate3 hold 3 floats per group. */
+int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* scale3,
+                             const float* translate3);
+
 /* Bytes of the packed device blob holding the last event's fragments. */
 size_t surtr_event_blob_bytes(const surtr_counts* counts);
 /* Packs the last event's fragments into one contiguous device buffer (for an

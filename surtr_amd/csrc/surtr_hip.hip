@@ -205,6 +205,26 @@ __global__ void k_place_cells(uint32_t nfaces, const float* __restrict__ v012, f
     planes[f] = plane_from_points(p, p + 3, p + 6);
 }
 
+// Same with one (scale, translate) per group of cells (recursive refracture: every first-level fragment places its own
+// cells in its own bounding box, Src/Surtr.cpp:1799-1803 applied per piece).
+__global__ void k_place_cells_groups(uint32_t nfaces, const float* __restrict__ v012, const uint32_t* __restrict__ face_group,
+                                     const float* __restrict__ scale3, const float* __restrict__ shift3, float4* __restrict__ planes)
+{
+    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nfaces) return;
+    const uint32_t g = face_group[f];
+    const float sx = scale3[3 * g], sy = scale3[3 * g + 1], sz = scale3[3 * g + 2];
+    const float tx = shift3[3 * g], ty = shift3[3 * g + 1], tz = shift3[3 * g + 2];
+    float p[9];
+    for (int i = 0; i < 3; ++i)
+    {
+        p[3 * i] = v012[9 * f + 3 * i] * sx + tx;
+        p[3 * i + 1] = v012[9 * f + 3 * i + 1] * sy + ty;
+        p[3 * i + 2] = v012[9 * f + 3 * i + 2] * sz + tz;
+    }
+    planes[f] = plane_from_points(p, p + 3, p + 6);
+}
+
 // ------------------------------------------------------------- arena output
 __device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
                                   uint32_t& voff, uint32_t& hoff, uint32_t& ioff)
@@ -342,7 +362,8 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
 __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs, const uint8_t* __restrict__ outside,
-                                                         ScratchPool pool, Arena A, PairRec* __restrict__ pairs)
+                                                         ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list)
 {
     __shared__ Shared sh;
     __shared__ LdsTopo L;
@@ -361,7 +382,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
-        const uint32_t cell = cell_begin + p / P.n, piece = p % P.n;
+        const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
+        const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         PairRec rec;
         memset(&rec, 0, sizeof(rec));
         bool skip = outside != nullptr && outside[piece] != 0;
@@ -409,7 +431,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4*
 __global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restrict__ pairs, uint32_t n_pairs,
                                                          uint32_t n_pieces, uint32_t cell_begin, Arena A,
                                                          uint2* __restrict__ blk, FragRec* __restrict__ frags,
-                                                         uint32_t cap_frags, surtr_counts* __restrict__ counts)
+                                                         uint32_t cap_frags, surtr_counts* __restrict__ counts,
+                                                         const uint2* __restrict__ pair_list)
 {
     __shared__ Shared sh;
     auto fn = [&](uint32_t p) -> uint2 { return make_uint2(pairs[p].ni, 0u); };
@@ -433,7 +456,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restri
                 {
                     const uint2 is = A.isl[r.isl_off + t];
                     FragRec fr;
-                    fr.cell = (int32_t)(cell_begin + p / n_pieces); fr.piece = (int32_t)(p % n_pieces); fr.island = (int32_t)t;
+                    fr.cell = (int32_t)(pair_list ? pair_list[p].x : cell_begin + p / n_pieces);
+                    fr.piece = (int32_t)(pair_list ? pair_list[p].y : p % n_pieces); fr.island = (int32_t)t;
                     fr.mv_off = vo; fr.mv_n = is.x; fr.mh_off = ho; fr.mh_n = is.y;
                     fr.cv_off = r.cv_off; fr.cv_n = r.cv_n; fr.ch_off = r.ch_off; fr.ch_n = r.ch_n;
                     fr.idx_off = 0; fr.idx_n = 0; fr.o_mv = fr.o_mh = fr.o_cv = fr.o_ch = fr.o_idx = 0;
@@ -1092,6 +1116,7 @@ struct surtr_ctx
     uint2* d_scanblk = nullptr; uint32_t cap_scanblk = 0;
     surtr_counts* d_counts = nullptr;
     uint8_t* d_outside = nullptr;
+    uint2* d_pair_list = nullptr; uint32_t cap_pair_list = 0;
     surtr_counts last{};
     bool have_event = false; uint32_t last_flags = 0;
     // staging for downloads
@@ -1176,7 +1201,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
     free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
-    free_dev(ctx->d_outside); free_dev(ctx->d_blob);
+    free_dev(ctx->d_outside); free_dev(ctx->d_blob); free_dev(ctx->d_pair_list);
     delete ctx;
 }
 
@@ -1463,13 +1488,9 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
     return SURTR_OK;
 }
 
-int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end, const uint8_t* outside, uint32_t flags)
+static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
-    if (!ctx) return SURTR_E_INVALID;
-    if (!ctx->n_pieces || !ctx->planes_ready) return SURTR_E_STATE;
-    if (cell_end > ctx->n_cells || cell_begin > cell_end) return SURTR_E_INVALID;
     (void)hipSetDevice(ctx->device);
-    const uint32_t n_pairs = (cell_end - cell_begin) * ctx->n_pieces;
     const uint32_t max_wg = ctx->max_wg;
     const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
     int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(n_wg, ctx->n_wg));
@@ -1491,11 +1512,11 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
     PROF_BEGIN(0);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool, ctx->arena, ctx->d_pairs);
+                           d_out, ctx->pool, ctx->arena, ctx->d_pairs, d_pair_list);
     PROF_END(0);
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
-                       ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts);
+                       ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list);
     PROF_END(1);
     if (flags & SURTR_EVT_REFIT)
     {
@@ -1515,6 +1536,67 @@ int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cel
     PROF_END(4);
     HIPCHK(hipGetLastError());
     ctx->have_event = true; ctx->last_flags = flags;
+    return SURTR_OK;
+}
+
+int surtr_fracture_event_async(surtr_ctx* ctx, uint32_t cell_begin, uint32_t cell_end, const uint8_t* outside, uint32_t flags)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    if (!ctx->n_pieces || !ctx->planes_ready) return SURTR_E_STATE;
+    if (cell_end > ctx->n_cells || cell_begin > cell_end) return SURTR_E_INVALID;
+    return launch_event(ctx, cell_begin, (cell_end - cell_begin) * ctx->n_pieces, nullptr, outside, flags);
+}
+
+int surtr_fracture_pairs_async(surtr_ctx* ctx, uint32_t n_pairs, const uint32_t* pair_cell, const uint32_t* pair_piece, uint32_t flags)
+{
+    if (!ctx || (n_pairs && (!pair_cell || !pair_piece))) return SURTR_E_INVALID;
+    if (!ctx->n_pieces || !ctx->planes_ready) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    std::vector<uint2> list(n_pairs);
+    for (uint32_t i = 0; i < n_pairs; ++i)
+    {
+        if (pair_cell[i] >= ctx->n_cells || pair_piece[i] >= ctx->n_pieces) return SURTR_E_INVALID;
+        list[i].x = pair_cell[i]; list[i].y = pair_piece[i];
+    }
+    if (ctx->cap_pair_list < std::max(n_pairs, 1u))
+    {
+        free_dev(ctx->d_pair_list); ctx->d_pair_list = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->d_pair_list, (size_t)std::max(n_pairs, 1u) * sizeof(uint2)));
+        ctx->cap_pair_list = std::max(n_pairs, 1u);
+    }
+    if (n_pairs) HIPCHK(hipMemcpyAsync(ctx->d_pair_list, list.data(), (size_t)n_pairs * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));     // `list` is a stack-owned staging buffer
+    return launch_event(ctx, 0, n_pairs, ctx->d_pair_list, nullptr, flags);
+}
+
+int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* scale3, const float* translate3)
+{
+    if (!ctx || !n_groups || !group_cell_off || !scale3 || !translate3) return SURTR_E_INVALID;
+    if (!ctx->d_v012) return SURTR_E_STATE;
+    if (group_cell_off[0] != 0 || group_cell_off[n_groups] != ctx->n_cells) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t nf = ctx->n_faces;
+    std::vector<uint32_t> face_group(std::max(nf, 1u));
+    for (uint32_t g = 0; g < n_groups; ++g)
+    {
+        if (group_cell_off[g + 1] < group_cell_off[g]) return SURTR_E_INVALID;
+        for (uint32_t c = group_cell_off[g]; c < group_cell_off[g + 1]; ++c)
+            for (uint32_t f = ctx->h_plane_off[c]; f < ctx->h_plane_off[c + 1]; ++f) face_group[f] = g;
+    }
+    uint32_t* d_fg = nullptr; float *d_s = nullptr, *d_t = nullptr;
+    auto cleanup = [&]() { free_dev(d_fg); free_dev(d_s); free_dev(d_t); };
+    if (hipMalloc((void**)&d_fg, (size_t)std::max(nf, 1u) * 4) != hipSuccess || hipMalloc((void**)&d_s, (size_t)n_groups * 12) != hipSuccess ||
+        hipMalloc((void**)&d_t, (size_t)n_groups * 12) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
+    hipError_t e = hipMemcpy(d_fg, face_group.data(), (size_t)nf * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_s, scale3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_t, translate3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cleanup(); return SURTR_E_HIP; }
+    if (nf)
+        hipLaunchKernelGGL(k_place_cells_groups, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, nf, ctx->d_v012, d_fg, d_s, d_t, ctx->d_planes);
+    e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) return SURTR_E_HIP;
+    ctx->planes_ready = true;
     return SURTR_OK;
 }
 

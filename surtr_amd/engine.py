@@ -171,6 +171,20 @@ class Engine:
         self._ck(lib().surtr_fracture_event_async(self._h, ctypes.c_uint32(cell_begin), ctypes.c_uint32(cell_end), _p(om),
                                                   ctypes.c_uint32(flags)))
 
+    def place_cells_groups(self, group_cell_off, scales, translates):
+        go = np.ascontiguousarray(group_cell_off, np.uint32)
+        s = np.ascontiguousarray(scales, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(translates, np.float32).reshape(-1, 3)
+        assert s.shape[0] == go.shape[0] - 1 == t.shape[0]
+        self._ck(lib().surtr_place_cells_groups(self._h, ctypes.c_uint32(s.shape[0]), _p(go), _p(s), _p(t)))
+
+    def fracture_pairs(self, pair_cell, pair_piece, flags=EVT_REFIT | EVT_RENDER):
+        pc = np.ascontiguousarray(pair_cell, np.uint32)
+        pp = np.ascontiguousarray(pair_piece, np.uint32)
+        assert pc.shape == pp.shape
+        self._ck(lib().surtr_fracture_pairs_async(self._h, ctypes.c_uint32(pc.shape[0]), _p(pc), _p(pp), ctypes.c_uint32(flags)))
+        return self.event_counts()
+
     def event_counts(self):
         c = Counts()
         self._ck(lib().surtr_event_counts(self._h, ctypes.byref(c)))

@@ -83,3 +83,39 @@ def blob_scene(n_cells=64):
 def torus_scene(n_cells=4096):
     v, t = meshgen.bumpy_torus()
     return make_scene(v, t, n_cells)
+
+
+def fragments_as_pieces(frags):
+    """Turns the fragment set of an event (engine.download / merge_fragments) into input pieces."""
+    meshes, convexes = [], []
+    for k in range(frags["frag_ids"].shape[0]):
+        for pre, out in (("mesh", meshes), ("conv", convexes)):
+            vo, no = frags[pre + "_vert_off"], frags[pre + "_nbr_off"]
+            a, b = int(vo[k]), int(vo[k + 1])
+            out.append({"pos": frags[pre + "_pos"][a:b].copy(), "off": (no[a:b + 1] - no[a]).astype(np.uint32),
+                        "nbr": frags[pre + "_nbr"][int(no[a]):int(no[b])].copy()})
+    return meshes, convexes
+
+
+def refracture_scene(meshes, convexes, cells_per_piece, seed=SEED):
+    """BASELINE configs[4] / SURVEY 8(d) cfg5: every first-level fragment gets `cells_per_piece` Voronoi cells drawn with
+    seed + fragment index and placed in that fragment's bounding box.  Returns the concatenated pattern, the
+    per-group placement and the fragment-major (cell, piece) pair list."""
+    face_off = [np.zeros(1, np.uint32)]
+    v012, scales, shifts, pair_cell, pair_piece = [], [], [], [], []
+    base_face, base_cell = 0, 0
+    for p, m in enumerate(meshes):
+        lo, hi = m["pos"].min(0), m["pos"].max(0)
+        scales.append((hi - lo).astype(np.float32))
+        shifts.append(((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32))
+        cells = engine.voronoi_cells(uniform_seeds(cells_per_piece, seed + p))
+        fo, v = engine.pattern_from_cells(cells)
+        face_off.append((fo[1:].astype(np.int64) + base_face).astype(np.uint32))
+        v012.append(v)
+        base_face += int(fo[-1])
+        pair_cell += list(range(base_cell, base_cell + cells_per_piece))
+        pair_piece += [p] * cells_per_piece
+        base_cell += cells_per_piece
+    return {"face_off": np.concatenate(face_off), "v012": np.concatenate(v012), "scales": np.array(scales, np.float32),
+            "shifts": np.array(shifts, np.float32), "group_cell_off": np.arange(0, base_cell + 1, cells_per_piece, dtype=np.uint32),
+            "pair_cell": np.array(pair_cell, np.uint32), "pair_piece": np.array(pair_piece, np.uint32), "n_cells": base_cell}

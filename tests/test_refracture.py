@@ -1,0 +1,54 @@
+"""BASELINE configs[4]: recursive refracture -- first-level fragments re-split by their own cells."""
+import numpy as np
+import pytest
+
+from helpers import assert_event_equal
+from surtr_amd import meshgen, scenes
+
+
+def _refracture(engine_mod, oracle, n_first, n_second, nu, nv):
+    sc = scenes.make_scene(*meshgen.bumpy_torus(nu, nv), n_first)
+    eng = engine_mod.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    eng.fracture_event(0, n_first, flags=1)
+    first = eng.download()
+    meshes, convexes = scenes.fragments_as_pieces(first)
+    # fragments with sliver faces are valid inputs too, but a ring that lists a neighbour twice has a degree-2
+    # neighbourhood the upload check rejects as in the reference's assertion; keep the regular ones
+    keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4]
+    meshes, convexes = [meshes[i] for i in keep], [convexes[i] for i in keep]
+    rs = scenes.refracture_scene(meshes, convexes, n_second)
+    eng.upload_pieces(meshes, convexes)
+    eng.upload_pattern(rs["face_off"], rs["v012"])
+    eng.place_cells_groups(rs["group_cell_off"], rs["scales"], rs["shifts"])
+    c = eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=3)
+    got = eng.download()
+    eng.close()
+    # oracle: piece by piece, its own cells, fragment-major
+    parts = []
+    for p in range(len(meshes)):
+        a, b = int(rs["group_cell_off"][p]), int(rs["group_cell_off"][p + 1])
+        f0, f1 = int(rs["face_off"][a]), int(rs["face_off"][b])
+        planes = oracle.place_cells(rs["v012"][f0:f1], rs["scales"][p], rs["shifts"][p])
+        ev = oracle.event([meshes[p]], [convexes[p]], rs["face_off"][a:b + 1] - rs["face_off"][a], planes, threads=4)
+        ev["frag_ids"] = ev["frag_ids"] + np.array([a, p, 0], np.int32)
+        parts.append(ev)
+    from surtr_amd import engine
+    ref = engine.merge_fragments(parts)
+    return c, got, ref, len(meshes)
+
+
+def test_refracture_emulated(emul_engine, oracle):
+    c, got, ref, npieces = _refracture(emul_engine, oracle, 12, 6, 48, 32)
+    assert npieces >= 6 and c.n_frag > npieces
+    assert_event_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_refracture_gpu(gpu_engine, oracle):
+    c, got, ref, npieces = _refracture(gpu_engine, oracle, 256, 32, 250, 200)
+    assert c.status == 0 and c.n_pairs == npieces * 32
+    assert npieces > 150 and c.n_frag > 2000
+    assert_event_equal(got, ref)
