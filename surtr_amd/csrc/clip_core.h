@@ -285,7 +285,7 @@ __device__ void relink_serial(Topo<TT>& T, uint32_t n0, uint32_t n1, const uint3
                 const uint32_t lc = T.llen[cur];
                 if (T.comp[cur] == 2)
                 {
-                    if (lc >= 3u) { SURTR_DBG("serial: comp2 ring full cur=%u\n", cur); sh.flagErr = 1; return; }
+                    if (lc >= cap[cur]) { SURTR_DBG("serial: comp2 ring full cur=%u\n", cur); sh.flagErr = 1; return; }
                     for (uint32_t q = lc; q > 0; --q) rc[q] = rc[q - 1];
                     rc[0] = (I)i;
                     T.llen[cur] = (typename TT::len_t)(lc + 1);
@@ -795,6 +795,8 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             }
             __syncthreads();
             // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
+            uint32_t* keptof = T.pcnt;     // kept end of every new vertex, for the back-link patch below
+            bool dup = false;
             for (uint32_t t = tid; t < M; t += SURTR_WG)
             {
                 const uint32_t v = srcv[t], j = srcj[t], fresh = n0 + t;
@@ -813,10 +815,38 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 const uint32_t lo = T.hUsed + 3u * t;
                 T.loff[fresh] = (typename TT::off_t)lo; T.llen[fresh] = 2;
                 T.ring[lo] = (I)v; T.ring[lo + 1] = (I)u; T.ring[lo + 2] = (I)TT::REM;
-                I* ru = T.ring + T.loff[u];
-                const uint32_t du = T.llen[u];
-                for (uint32_t q = 0; q < du; ++q) if ((uint32_t)ru[q] == v) { ru[q] = (I)fresh; break; }
-                r[j] = (I)fresh;
+                keptof[t] = u;
+                // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
+                for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u) dup = true;
+            }
+            if (dup) sh.flagBad = 1;
+            __syncthreads();
+            const bool ordered = sh.flagBad != 0;
+            __syncthreads();
+            if (tid == 0) sh.flagBad = 0;
+            // links of the two ends (:350-354): "find the clipped vertex in the kept vertex's ring, overwrite it"
+            if (!ordered)
+            {
+                for (uint32_t t = tid; t < M; t += SURTR_WG)
+                {
+                    const uint32_t v = srcv[t], u = keptof[t], fresh = n0 + t;
+                    I* ru = T.ring + T.loff[u];
+                    const uint32_t du = T.llen[u];
+                    for (uint32_t q = 0; q < du; ++q) if ((uint32_t)ru[q] == v) { ru[q] = (I)fresh; break; }
+                    T.ring[T.loff[v] + srcj[t]] = (I)fresh;
+                }
+            }
+            else if (tid == 0)
+            {
+                COUNT(39);
+                for (uint32_t t = 0; t < M; ++t)        // reference order: first remaining occurrence each time
+                {
+                    const uint32_t v = srcv[t], u = keptof[t], fresh = n0 + t;
+                    I* ru = T.ring + T.loff[u];
+                    const uint32_t du = T.llen[u];
+                    for (uint32_t q = 0; q < du; ++q) if ((uint32_t)ru[q] == v) { ru[q] = (I)fresh; break; }
+                    T.ring[T.loff[v] + srcj[t]] = (I)fresh;
+                }
             }
         }
         uint32_t hend = T.hUsed + 3u * M;
@@ -874,31 +904,67 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         if (serial)
         {
             COUNT(19);
-            // give every in-plane vertex a ring with room for insertions plus its snapshot
-            uint32_t* snapoff = T.aux0; uint32_t* cap = T.aux1; uint32_t* zlist = T.aux2;
+            // Dry run (parallel): how many walks end on each surviving vertex = an upper bound of the insertions it
+            // receives (:404-421).  Walks only traverse rings of clipped vertices, which the relink never modifies,
+            // so their targets do not depend on the processing order.
+            uint32_t* snapoff = T.aux0; uint32_t* cap = T.aux1; uint32_t* zlist = T.aux2; uint32_t* arrive = T.pcnt;
+            for (uint32_t v = tid; v < n1; v += SURTR_WG) arrive[v] = 0;
+            __syncthreads();
+            for (uint32_t v = tid; v < n1; v += SURTR_WG)
+            {
+                const int cv = T.comp[v];
+                if (!(cv == 0 || cv == 2)) continue;
+                const I* r = T.ring + T.loff[v];
+                const uint32_t deg = T.llen[v];
+                for (uint32_t j = 0; j < deg; ++j)
+                {
+                    const uint32_t jn = r[j];
+                    if (jn >= TT::SENT || T.comp[jn] != -1) continue;
+                    uint32_t prev = v, c = jn, steps = 0;
+                    while (c < TT::SENT && T.comp[c] == -1 && steps++ < n1)
+                    {
+                        const uint32_t hold = c;
+                        c = face_next(T.ring + T.loff[c], T.llen[c], prev);
+                        prev = hold;
+                    }
+                    if (c < TT::SENT && c != v) atomicAdd(&arrive[c], 1u);
+                }
+            }
+            __syncthreads();
+            // every in-plane vertex gets a ring with room for its arrivals plus the old_neighbors snapshot (:367-369);
+            // a new vertex keeps its 3 slots unless more than one walk ends on it (degenerate input rings)
             auto zfn = [&](uint32_t v) -> uint2 {
-                return (T.comp[v] == 0) ? make_uint2(1u, 4u * (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
+                const int cv = T.comp[v];
+                if (cv == 0) return make_uint2(v < n0 ? 1u : 0u, 2u * ((uint32_t)T.llen[v] + arrive[v]));
+                if (cv == 2 && arrive[v] > 1u) return make_uint2(0u, (uint32_t)T.llen[v] + arrive[v]);
+                return make_uint2(0u, 0u);
             };
             uint32_t zc = 0, zw = 0;
-            scan_blocks(n0, T.blk, sh, zfn, zc, zw);
+            scan_blocks(n1, T.blk, sh, zfn, zc, zw);
             if (hend + zw > T.capH) { COUNT(37); return SURTR_OVERFLOW; }
-            const uint32_t nb = (n0 + SURTR_LANES - 1u) >> SURTR_LSH;
+            const uint32_t nb = (n1 + SURTR_LANES - 1u) >> SURTR_LSH;
             bool toolong = false;
             for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
             {
                 const uint32_t v = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
-                if (v < n0) c = zfn(v);
+                if (v < n1) c = zfn(v);
                 const uint2 e = wave_excl2(c);
-                if (v < n0 && c.x)
+                if (v < n1)
                 {
+                    const int cv = T.comp[v];
                     const uint32_t len = T.llen[v];
-                    const uint32_t dst = hend + T.blk[b].y + e.y;
-                    const I* src = T.ring + T.loff[v];
-                    for (uint32_t q = 0; q < len; ++q) { T.ring[dst + q] = src[q]; T.ring[dst + 2u * len + q] = src[q]; }
-                    T.loff[v] = (typename TT::off_t)dst; snapoff[v] = dst + 2u * len; cap[v] = 2u * len;
-                    zlist[T.blk[b].x + e.x] = v;
-                    if (2u * len > TT::MAXLEN) toolong = true;
+                    if (c.y)
+                    {
+                        const uint32_t room = len + arrive[v];
+                        const uint32_t dst = hend + T.blk[b].y + e.y;
+                        const I* src = T.ring + T.loff[v];
+                        for (uint32_t q = 0; q < len; ++q) { T.ring[dst + q] = src[q]; if (cv == 0) T.ring[dst + room + q] = src[q]; }
+                        T.loff[v] = (typename TT::off_t)dst; snapoff[v] = dst + room; cap[v] = room;
+                        if (room > TT::MAXLEN) toolong = true;
+                    }
+                    else if (cv == 2) cap[v] = 3u;
+                    if (c.x) zlist[T.blk[b].x + e.x] = v;
                 }
             }
             if (toolong) sh.flagBad = 1;
