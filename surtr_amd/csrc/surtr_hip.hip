@@ -359,7 +359,10 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
 }
 
 // -------------------------------------------------------------- k_clip_pairs
-__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
+#ifndef SURTR_CLIP_MINWAVES
+#define SURTR_CLIP_MINWAVES 1
+#endif
+__global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                          ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
@@ -722,6 +725,97 @@ __device__ static uint32_t ear_clip_face(const float* pos, const int32_t* loop, 
     return at + 3;
 }
 
+#ifndef SURTR_EMUL
+// Poly::EarClipping for one face of 5..64 vertices on one wave: lane i holds vertex i (position, prev/next
+// link, reflex flag) in registers; the sequential ear loop (:868-906) runs wave-uniformly, and the scan of the
+// reflex list (:837-856, an "any reflex vertex inside the candidate ear") is one ballot.  Same triangles, same
+// order, same stall rule as ear_clip_face.
+__device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* loop, int N, uint32_t* out)
+{
+    const int lane = (int)lane_id();
+    const bool mine = lane < N;
+    const int32_t vid = loop[mine ? lane : 0];
+    const float x = pos[3 * vid], y = pos[3 * vid + 1], z = pos[3 * vid + 2];
+    auto bx = [&](int i) { return __shfl(x, i, 64); };
+    auto by = [&](int i) { return __shfl(y, i, 64); };
+    auto bz = [&](int i) { return __shfl(z, i, 64); };
+    const float ax0 = bx(0), ay0 = by(0), az0 = bz(0);
+    float nx, ny, nz;
+    {
+        const float ux = bx(1) - ax0, uy = by(1) - ay0, uz = bz(1) - az0;
+        const float wx = bx(2) - ax0, wy = by(2) - ay0, wz = bz(2) - az0;
+        nx = uy * wz - uz * wy; ny = uz * wx - ux * wz; nz = ux * wy - uy * wx;
+    }
+    {   // IsCCW (:753-762): the sum runs over v = 0..N-1 in order (float addition is not associative)
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int v = 0; v < N; ++v)
+        {
+            const int q = (v + 1) % N;
+            const float ux = bx(v) - ax0, uy = by(v) - ay0, uz = bz(v) - az0;
+            const float wx = bx(q) - ax0, wy = by(q) - ay0, wz = bz(q) - az0;
+            sx = sx + (uy * wz - uz * wy); sy = sy + (uz * wx - ux * wz); sz = sz + (ux * wy - uy * wx);
+        }
+        if (dot3(sx, sy, sz, nx, ny, nz) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    }
+    int prv = (lane + N - 1) % N, nxt = (lane + 1) % N;
+    auto right_of = [&](float ax, float ay, float az, float bx_, float by_, float bz_, float cx, float cy, float cz) {
+        const float ux = bx_ - ax, uy = by_ - ay, uz = bz_ - az;
+        const float wx = cx - ax, wy = cy - ay, wz = cz - az;
+        const float kx = uy * wz - uz * wy, ky = uz * wx - ux * wz, kz = ux * wy - uy * wx;
+        return dot3(kx, ky, kz, nx, ny, nz) > 0.f;
+    };
+    bool rfx = false;
+    {
+        const float px_ = bx(prv), py_ = by(prv), pz_ = bz(prv), qx = bx(nxt), qy = by(nxt), qz = bz(nxt);
+        rfx = mine && !right_of(px_, py_, pz_, x, y, z, qx, qy, qz);
+    }
+    int skipped = 0, left = N, cur = 0;
+    uint32_t at = 0;
+    while (left > 3)
+    {
+        const int p = __shfl(prv, cur, 64), n = __shfl(nxt, cur, 64);
+        const bool cur_reflex = __shfl((int)rfx, cur, 64) != 0;
+        bool ear = !cur_reflex;
+        if (ear)
+        {
+            const float ax = bx(p), ay = by(p), az = bz(p);
+            const float cx_ = bx(cur), cy_ = by(cur), cz_ = bz(cur);
+            const float ex = bx(n), ey = by(n), ez = bz(n);
+            bool inside = false;
+            if (mine && rfx && lane != p && lane != n)
+            {
+                const bool same = (x == ax && y == ay && z == az) || (x == cx_ && y == cy_ && z == cz_);
+                if (!same)
+                    inside = right_of(ax, ay, az, cx_, cy_, cz_, x, y, z) && right_of(cx_, cy_, cz_, ex, ey, ez, x, y, z) &&
+                             right_of(ex, ey, ez, ax, ay, az, x, y, z);
+            }
+            ear = __ballot(inside) == 0ull;
+        }
+        if (ear)
+        {
+            if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
+            if (lane == p) nxt = n;
+            if (lane == n) prv = p;
+            // reflex flags of the two neighbours, only if they were reflex (:885-893)
+            // (all broadcasts are done by the whole wave; only the two lanes use them)
+            const int np = __shfl(prv, p, 64), nn = __shfl(nxt, n, 64);
+            const float npx = bx(np), npy = by(np), npz = bz(np), nnx = bx(nn), nny = by(nn), nnz = bz(nn);
+            const float ppx = bx(p), ppy = by(p), ppz = bz(p), qqx = bx(n), qqy = by(n), qqz = bz(n);
+            if (lane == p && rfx) rfx = !right_of(npx, npy, npz, x, y, z, qqx, qqy, qqz);
+            if (lane == n && rfx) rfx = !right_of(ppx, ppy, ppz, x, y, z, nnx, nny, nnz);
+            at += 3; --left; skipped = 0;
+        }
+        else if (++skipped > left) return 0;             // stalled: the face is dropped (:899-903)
+        cur = n;
+    }
+    {
+        const int p = __shfl(prv, cur, 64), n = __shfl(nxt, cur, 64);
+        if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
+    }
+    return at + 3;
+}
+#endif
+
 __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
                                                     Arena A)
@@ -888,10 +982,23 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
         }
         __syncthreads();
-        // 4. triangulate every face on its own lane; room for 3*len indices at 3*lo
+        // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
+        //    room for 3*len indices at 3*lo
+#ifndef SURTR_EMUL
+        for (uint32_t fi = wave_id(); fi < nfaces; fi += SURTR_NWAVE)
+        {
+            const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
+            if (len < 5u || len > 64u) continue;
+            const uint32_t cnt = ear_clip_face_wave(pos, loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
+            if (lane_id() == 0) fcnt[fi] = cnt;
+        }
+#endif
         for (uint32_t fi = tid; fi < nfaces; fi += SURTR_WG)
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
+#ifndef SURTR_EMUL
+            if (len >= 5u && len <= 64u) continue;
+#endif
             uint32_t* out = tri + 3u * (size_t)lo;
             fcnt[fi] = (len >= 3u) ? ear_clip_face(pos, loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out) : 0u;
         }
