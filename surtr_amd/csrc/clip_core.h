@@ -233,6 +233,19 @@ __device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t&
 template <class I>
 __device__ __forceinline__ uint32_t face_next(const I* ring, uint32_t len, uint32_t prev)
 {
+    if (len <= 4u)
+    {
+        // the common case (new vertices have 3 entries, most others <= 4): fetch the whole ring at once so a walk
+        // step costs one LDS round trip instead of one per entry; indices are clamped, so no read leaves the ring
+        const uint32_t l1 = len > 1u ? 1u : 0u, l2 = len > 2u ? 2u : 0u, l3 = len > 3u ? 3u : 0u;
+        const uint32_t e0 = ring[0], e1 = ring[l1], e2 = ring[l2], e3 = ring[l3];
+        const uint32_t last = len == 4u ? e3 : (len == 3u ? e2 : (len == 2u ? e1 : e0));
+        if (e0 == prev) return last;
+        if (len > 1u && e1 == prev) return e0;
+        if (len > 2u && e2 == prev) return e1;
+        if (len > 3u && e3 == prev) return e2;
+        return last;     // not found: std::find returns end(), the reference then reads *(end-1)
+    }
     uint32_t k = 0;
     while (k < len && (uint32_t)ring[k] != prev) ++k;
     if (k == 0) return (uint32_t)ring[len - 1];
@@ -752,7 +765,17 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             {
                 const I* r = T.ring + T.loff[v];
                 const uint32_t deg = T.llen[v];
-                for (uint32_t j = 0; j < deg; ++j) { const uint32_t u = r[j]; if (u < TT::SENT && T.comp[u] > 0) ++c; }
+                for (uint32_t j0 = 0; j0 < deg; j0 += 4)
+                {
+                    // four entries per round trip: ring entries first, then their comp bytes (indices clamped into the ring)
+                    uint32_t u[4]; int cu[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) u[q] = r[j0 + q < deg ? j0 + q : deg - 1u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) cu[q] = T.comp[u[q] < TT::SENT ? u[q] : 0u];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (j0 + q < deg && u[q] < TT::SENT && cu[q] > 0) ++c;
+                }
                 cutcnt[v] = c;         // only clipped vertices are written and read back (scratch traffic)
             }
             return make_uint2(c, 1u);
