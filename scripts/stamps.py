@@ -21,6 +21,7 @@ for i, n in enumerate(names):
 print("total cycles (lane0, summed over WGs)", tot)
 print("serial planes", buf[19], "solids redone on global scratch", buf[20], "squeezes", buf[31])
 print("overflow causes: toolong %d, n>capV %d, hsum>capEmit %d, M>capAux %d, after squeeze %d, zw %d, ring len %d" % tuple(buf[32:39]))
+print("walks: %d walkers, %d steps (avg %.2f); per plane: %d planes, sum of max walk %d (avg max %.1f), walker rounds %d" % (buf[41], buf[40], buf[40]/max(buf[41],1), buf[43], buf[42], buf[42]/max(buf[43],1), buf[44]))
 print("pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[21 + i] for i in range(11)])
 print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[18], 1), buf[17], buf[18]))
 eng.close()

@@ -126,6 +126,7 @@ struct Shared
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t wsum[2 * SURTR_NWAVE];
     uint32_t flagCut, flagKeep, flagZero, flagBad, flagErr;
+    uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;
     uint32_t misc[8];
 };
@@ -679,13 +680,17 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
     STAMP_DECL;
     if (T.nLive == 0) return 0;
     bool squeezed = false;
+    uint32_t it = 0;
+    for (uint32_t q = tid; q < 24; q += SURTR_WG) (&sh.pf[0][0])[q] = 0;
+    __syncthreads();
     for (uint32_t k = 0; k < F; ++k)
     {
         const float4 pl = sh.planes[k];
         const uint32_t nS = T.nS;
-        __syncthreads();     // every lane has read the previous plane's flags before they are reset
-        if (tid == 0) { sh.flagCut = 0; sh.flagKeep = 0; sh.flagZero = 0; sh.flagBad = 0; }
-        __syncthreads();
+        // Per-plane flags are triple buffered so that no barrier is spent on resetting them: set (it+2)%3 is cleared
+        // right after this plane's first barrier -- every lane has finished reading it (plane it-1) by then, and nobody
+        // writes it before the first barrier of plane it+1.  `it` counts loop passes (a squeeze retries a plane).
+        uint32_t* pf = sh.pf[it % 3u];
         // ---- classify (:307-318) ----
         {
             bool anyc = false, anyk = false, anyz = false;
@@ -696,13 +701,15 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 T.comp[v] = (int8_t)c;
                 anyc |= c < 0; anyk |= c > 0; anyz |= c == 0;
             }
-            if (anyc) sh.flagCut = 1;
-            if (anyk) sh.flagKeep = 1;
-            if (anyz) sh.flagZero = 1;
+            if (anyc) pf[0] = 1;
+            if (anyk) pf[1] = 1;
+            if (anyz) pf[2] = 1;
         }
         __syncthreads();
+        if (tid == 0) { uint32_t* nx = sh.pf[(it + 2u) % 3u]; for (int q = 0; q < 8; ++q) nx[q] = 0; }
+        ++it;
         STAMP(4);
-        const bool anyCut = sh.flagCut != 0, anyKeep = sh.flagKeep != 0, anyZero = sh.flagZero != 0;
+        const bool anyCut = pf[0] != 0, anyKeep = pf[1] != 0, anyZero = pf[2] != 0;
         const uint32_t dropAlive = sh.hist[k];
         const uint32_t dropKept = dropAlive - sh.zhist[k];   // dropped vertices strictly on the kept side of this plane
         if (!anyCut && !anyKeep && dropKept == 0)
@@ -799,6 +806,9 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             const uint32_t nb = (n0 + SURTR_LANES - 1u) >> SURTR_LSH;
             for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
             {
+                // blocks that produce no new vertex (most of them) are skipped without touching memory
+                const uint32_t first = T.blk[b].x, beyond = (b + 1u < nb) ? T.blk[b + 1u].x : M;
+                if (first == beyond) continue;
                 const uint32_t v = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
                 if (v < n0 && T.comp[v] == -1) c.x = cutcnt[v];
@@ -818,7 +828,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             }
             __syncthreads();
             // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
-            uint32_t* keptof = T.pcnt;     // kept end of every new vertex, for the back-link patch below
+            uint32_t* keptof = T.aux1;     // kept end of every new vertex, for the back-link patch below
             bool dup = false;
             for (uint32_t t = tid; t < M; t += SURTR_WG)
             {
@@ -839,14 +849,13 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 T.loff[fresh] = (typename TT::off_t)lo; T.llen[fresh] = 2;
                 T.ring[lo] = (I)v; T.ring[lo + 1] = (I)u; T.ring[lo + 2] = (I)TT::REM;
                 keptof[t] = u;
+                T.pcnt[t] = 0;             // predecessor count of the relink below
                 // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
                 for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u) dup = true;
             }
-            if (dup) sh.flagBad = 1;
+            if (dup) pf[3] = 1;
             __syncthreads();
-            const bool ordered = sh.flagBad != 0;
-            __syncthreads();
-            if (tid == 0) sh.flagBad = 0;
+            const bool ordered = pf[3] != 0;
             // links of the two ends (:350-354): "find the clipped vertex in the kept vertex's ring, overwrite it"
             if (!ordered)
             {
@@ -882,8 +891,6 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         {
             // regular cap: every new vertex X=[cut, kept] finds its successor by walking the face
             // loop through clipped vertices; its final ring is [pred, succ, kept].
-            for (uint32_t t = tid; t < M; t += SURTR_WG) T.pcnt[t] = 0;
-            __syncthreads();
             bool bad = false;
             for (uint32_t t = tid; t < M; t += SURTR_WG)
             {
@@ -895,6 +902,9 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     c = face_next(T.ring + T.loff[c], T.llen[c], prev);
                     prev = hold;
                 }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+                atomicAdd(&g_stamp[40], (unsigned long long)steps); atomicAdd(&g_stamp[41], 1ull); atomicMax(&sh.misc[5], steps);
+#endif
                 if (c >= TT::SENT || c < n0 || c == X || T.comp[c] != 2) { bad = true; T.succ[t] = X; }
                 else
                 {
@@ -903,13 +913,16 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     T.pred[c - n0] = X;
                 }
             }
-            if (bad) sh.flagBad = 1;
+            if (bad) pf[4] = 1;
             __syncthreads();
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+            if (tid == 0) { atomicAdd(&g_stamp[42], (unsigned long long)sh.misc[5]); atomicAdd(&g_stamp[43], 1ull); atomicAdd(&g_stamp[44], (unsigned long long)((M + SURTR_WG - 1) / SURTR_WG)); sh.misc[5] = 0; }
+#endif
             bad = false;
             for (uint32_t t = tid; t < M; t += SURTR_WG) if (T.pcnt[t] != 1u) bad = true;
-            if (bad) sh.flagBad = 1;
+            if (bad) pf[4] = 1;
             __syncthreads();
-            serial = sh.flagBad != 0;
+            serial = pf[4] != 0;
             if (!serial)
             {
                 for (uint32_t t = tid; t < M; t += SURTR_WG)
@@ -920,9 +933,6 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     T.llen[n0 + t] = 3;
                 }
             }
-            __syncthreads();
-            if (tid == 0) sh.flagBad = 0;
-            __syncthreads();
         }
         if (serial)
         {
@@ -990,10 +1000,10 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     if (c.x) zlist[T.blk[b].x + e.x] = v;
                 }
             }
-            if (toolong) sh.flagBad = 1;
+            if (toolong) pf[6] = 1;
             hend += zw;
             __syncthreads();
-            if (sh.flagBad) { COUNT(38); return SURTR_OVERFLOW; }     // a ring could outgrow this Topo's length type
+            if (pf[6]) { COUNT(38); return SURTR_OVERFLOW; }     // a ring could outgrow this Topo's length type
             if (tid == 0) relink_serial(T, n0, n1, snapoff, cap, zlist, zc, sh);
             __syncthreads();
             if (sh.flagErr) return 2;
@@ -1024,14 +1034,13 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         __syncthreads();     // rings and lengths of this plane are final
         STAMP(6);
         // ---- tombstones instead of the per-plane compaction (:464-495); live count for :497-499 ----
-        if (tid == 0) sh.misc[1] = 0;
-        __syncthreads();
         {
             uint32_t live = 0; bool dangling = false;
             for (uint32_t v = tid; v < n1; v += SURTR_WG)
             {
                 const int c = T.comp[v];
-                if (c == SURTR_DEAD || c < 0) continue;
+                if (c == SURTR_DEAD) continue;
+                if (c < 0) { if (!serial) T.comp[v] = SURTR_DEAD; continue; }
                 ++live;
                 if (!serial) continue;       // a regular plane cannot leave such links (every one was replaced by a new vertex)
                 const I* r = T.ring + T.loff[v];
@@ -1043,13 +1052,16 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 }
             }
             if (dangling) { SURTR_DBG("plane %u: live vertex links a clipped one\n", k); sh.flagErr = 1; }
-            if (live) atomicAdd(&sh.misc[1], live);
+            if (live) atomicAdd(&pf[5], live);
         }
         __syncthreads();
         if (sh.flagErr) return 2;
-        for (uint32_t v = tid; v < n1; v += SURTR_WG) if (T.comp[v] < 0) T.comp[v] = SURTR_DEAD;
-        T.nS = n1; T.hUsed = hend; T.nLive = sh.misc[1];
-        __syncthreads();
+        if (serial)
+        {
+            for (uint32_t v = tid; v < n1; v += SURTR_WG) if (T.comp[v] < 0) T.comp[v] = SURTR_DEAD;
+            __syncthreads();
+        }
+        T.nS = n1; T.hUsed = hend; T.nLive = pf[5];
         STAMP(7);
         if (T.nLive + dropAlive < 4u) { T.nLive = 0; break; }
     }
