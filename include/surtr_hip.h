@@ -175,6 +175,15 @@ int surtr_neighbors_from_mesh(uint32_t nv, uint32_t n_tris, const int32_t* tris,
 int surtr_voronoi_cells(uint32_t n, const double* seeds, uint32_t* n_faces, uint32_t* n_face_verts,
                         uint32_t* cell_face_off, int32_t* face_gen, uint32_t* face_vert_off, double* verts);
 
+/* VMACH::ConvexHull(points, limit) + Surtr::GenerateICHNormal (Src/VMACH.cpp:869-1161, Src/Surtr.cpp:1961-1974):
+ * unit normals of the faces of the greedy limited hull, in face creation order.  Count-then-fill. */
+int surtr_hull_normals(uint32_t n, const float* points, uint32_t limit, uint32_t capacity, float* normals, uint32_t* count);
+
+/* Kdop::KdopContainer::Calc(vertices, maxAxisScale, planeGapInv) (Src/Kdop.cpp:15-51): for every normal the Min
+ * plane then the Max plane (the order ClipWithPolyhedron clips in, :166-179); planes holds 8 floats per normal. */
+int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const float* normals, double max_axis_scale,
+                          float plane_gap_inv, float* planes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -289,6 +290,213 @@ int surtr_voronoi_cells(uint32_t n, const double* seeds, uint32_t* n_faces, uint
         if (fill) cell_face_off[c + 1] = nf;
     }
     *n_faces = nf; *n_face_verts = nfv;
+    return SURTR_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// Limited greedy convex hull -> unit face normals (VMACH::ConvexHull with a point limit,
+// Src/VMACH.cpp:869-1161, + Surtr::GenerateICHNormal, Src/Surtr.cpp:1961-1974), index-based: faces and
+// edges live in vectors in creation order with tombstones instead of std::list nodes.  Edges are keyed like the
+// reference's Key2Edge (:941-948): by the "%f" text of their end points, so two points that print alike share a key.
+namespace {
+
+struct F3 { float x, y, z; };
+inline F3 f3sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline bool f3eq(F3 a, F3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+struct LimitedHull
+{
+    struct Face { F3 v[3]; bool visible = false, dead = false; };
+    struct Edge { F3 e[2]; int f1 = -1, f2 = -1; bool remove = false, dead = false; std::string key; };
+    std::vector<F3> pts; std::vector<char> done; std::vector<float> gain;
+    std::vector<Face> faces; std::vector<Edge> edges;
+    std::unordered_map<std::string, int> emap;
+    std::vector<int> added, visible;
+
+    static float vol(const Face& f, F3 p)                             // :922-939
+    {
+        const float ax = f.v[0].x - p.x, ay = f.v[0].y - p.y, az = f.v[0].z - p.z;
+        const float bx = f.v[1].x - p.x, by = f.v[1].y - p.y, bz = f.v[1].z - p.z;
+        const float cx = f.v[2].x - p.x, cy = f.v[2].y - p.y, cz = f.v[2].z - p.z;
+        return ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx);
+    }
+    static std::string text(F3 p) { return std::to_string(p.x) + std::to_string(p.y) + std::to_string(p.z); }
+    static std::string key(F3 a, F3 b) { std::string s = text(a), t = text(b); return s < t ? s + "|" + t : t + "|" + s; }
+    void edge(F3 a, F3 b, int face)                                   // CreateEdge :971-983 + LinkFace
+    {
+        const std::string k = key(a, b);
+        auto it = emap.find(k);
+        if (it == emap.end())
+        {
+            Edge e; e.e[0] = a; e.e[1] = b; e.key = k;
+            edges.push_back(e);
+            it = emap.emplace(k, (int)edges.size() - 1).first;
+        }
+        Edge& e = edges[it->second];
+        if (e.f1 >= 0 && e.f2 >= 0) return;
+        (e.f1 < 0 ? e.f1 : e.f2) = face;
+    }
+    void face(F3 a, F3 b, F3 c, F3 inner)                             // CreateFace :955-969
+    {
+        Face f; f.v[0] = a; f.v[1] = b; f.v[2] = c;
+        if (vol(f, inner) < 0.f) std::swap(f.v[0], f.v[2]);
+        faces.push_back(f);
+        const int id = (int)faces.size() - 1;
+        added.push_back(id);
+        edge(a, b, id); edge(a, c, id); edge(b, c, id);
+    }
+    bool first()                                                      // BuildFirstHull :1036-1085
+    {
+        const size_t n = pts.size();
+        if (n <= 3) return false;
+        size_t i1 = 0;
+        for (size_t i = 1; i < n; ++i) if (pts[i1].x < pts[i].x) i1 = i;
+        auto dist = [&](F3 a) {
+            const double dx = (double)(a.x - pts[i1].x), dy = (double)(a.y - pts[i1].y), dz = (double)(a.z - pts[i1].z);
+            return std::sqrt(dx * dx + dy * dy + dz * dz);
+        };
+        size_t i2 = 0;
+        for (size_t i = 1; i < n; ++i) if (dist(pts[i2]) < dist(pts[i])) i2 = i;
+        auto area = [&](F3 c) {
+            const F3 u = f3sub(pts[i2], pts[i1]), w = f3sub(c, pts[i1]);
+            const float kx = u.y * w.z - u.z * w.y, ky = u.z * w.x - u.x * w.z, kz = u.x * w.y - u.y * w.x;
+            float t = kx * kx + ky * ky; t = t + kz * kz;
+            return 0.5f * std::sqrt(t);
+        };
+        size_t i3 = 0;
+        for (size_t i = 1; i < n; ++i) if (area(pts[i3]) < area(pts[i])) i3 = i;
+        Face base; base.v[0] = pts[i1]; base.v[1] = pts[i2]; base.v[2] = pts[i3];
+        size_t i4 = 0;
+        for (size_t i = 1; i < n; ++i) if (vol(base, pts[i4]) < vol(base, pts[i])) i4 = i;
+        done[i1] = done[i2] = done[i3] = done[i4] = 1;
+        face(pts[i1], pts[i2], pts[i3], pts[i4]);
+        face(pts[i1], pts[i2], pts[i4], pts[i3]);
+        face(pts[i1], pts[i3], pts[i4], pts[i2]);
+        face(pts[i2], pts[i3], pts[i4], pts[i1]);
+        return true;
+    }
+    void add_point(F3 p)                                              // AddPointToHull :994-1034
+    {
+        bool any = false;
+        for (size_t f = 0; f < faces.size(); ++f)
+            if (!faces[f].dead && vol(faces[f], p) < 0.f) { faces[f].visible = true; visible.push_back((int)f); any = true; }
+        if (!any) return;
+        for (size_t i = 0; i < edges.size(); ++i)                      // edges appended below are visited too, like the list
+        {
+            if (edges[i].dead) continue;
+            int f1 = edges[i].f1, f2 = edges[i].f2;
+            if (f1 < 0 || f2 < 0) continue;
+            const bool v1 = faces[f1].visible, v2 = faces[f2].visible;
+            if (v1 && v2) { edges[i].remove = true; continue; }
+            if (!(v1 || v2)) continue;
+            if (v1) { std::swap(f1, f2); edges[i].f1 = f1; edges[i].f2 = f2; }
+            F3 inner = faces[f2].v[0];
+            for (int q = 0; q < 3; ++q)
+                if (!f3eq(faces[f2].v[q], edges[i].e[0]) && !f3eq(faces[f2].v[q], edges[i].e[1])) { inner = faces[f2].v[q]; break; }
+            if (edges[i].f1 == f2) edges[i].f1 = -1; else edges[i].f2 = -1;          // EraseFace(face2)
+            const F3 a = edges[i].e[0], b = edges[i].e[1];
+            face(a, b, p, inner);                                      // may grow `edges`
+        }
+    }
+    void cleanup()                                                    // :1140-1161
+    {
+        visible.clear(); added.clear();
+        for (auto& e : edges) if (!e.dead && e.remove) { emap.erase(e.key); e.dead = true; }
+        for (auto& f : faces) if (!f.dead && f.visible) f.dead = true;
+    }
+    void build(uint32_t limit)                                        // CreateConvexHull :1087-1138
+    {
+        done.assign(pts.size(), 0); gain.assign(pts.size(), 0.f);
+        if (!first()) return;
+        uint32_t used = 4;
+        for (size_t i = 0; i < pts.size(); ++i)
+        {
+            if (done[i]) continue;
+            for (const Face& f : faces) gain[i] += std::max(0.0f, vol(f, pts[i]));
+        }
+        if (limit == 0) limit = (uint32_t)pts.size();
+        while (used < limit)
+        {
+            size_t k = 0;
+            for (size_t i = 1; i < gain.size(); ++i) if (gain[k] < gain[i]) k = i;
+            add_point(pts[k]);
+            done[k] = 1; gain[k] = -3.402823466e+38f; ++used;
+            for (size_t i = 0; i < pts.size(); ++i)
+            {
+                if (done[i]) continue;
+                float gone = 0.f, came = 0.f;
+                for (int f : visible) gone += std::max(0.0f, vol(faces[f], pts[i]));
+                for (int f : added) came += std::max(0.0f, vol(faces[f], pts[i]));
+                gain[i] -= gone; gain[i] += came;
+            }
+            cleanup();
+        }
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int surtr_hull_normals(uint32_t n, const float* points, uint32_t limit, uint32_t capacity, float* normals, uint32_t* count)
+{
+    if (!points || !count) return SURTR_E_INVALID;
+    LimitedHull h;
+    h.pts.resize(n);
+    for (uint32_t i = 0; i < n; ++i) h.pts[i] = F3{points[3 * i], points[3 * i + 1], points[3 * i + 2]};
+    h.build(limit);
+    uint32_t m = 0;
+    for (const auto& f : h.faces)
+    {
+        if (f.dead) continue;
+        if (normals && m < capacity)
+        {
+            const F3 u = f3sub(f.v[1], f.v[0]), w = f3sub(f.v[2], f.v[0]);
+            float nx = u.y * w.z - u.z * w.y, ny = u.z * w.x - u.x * w.z, nz = u.x * w.y - u.y * w.x;
+            float t = nx * nx + ny * ny; t = t + nz * nz;
+            const float len = std::sqrt(t);
+            if (len != 0.f) { nx = nx / len; ny = ny / len; nz = nz / len; } else { nx = ny = nz = 0.f; }
+            normals[3 * m] = nx; normals[3 * m + 1] = ny; normals[3 * m + 2] = nz;
+        }
+        ++m;
+    }
+    *count = m;
+    return (normals && m > capacity) ? SURTR_E_CAPACITY : SURTR_OK;
+}
+
+// Kdop::KdopContainer::Calc(vertices, maxAxisScale, planeGapInv) (Src/Kdop.cpp:15-51) + the plane order of
+// ClipWithPolyhedron (:166-179): for every normal the Min plane then the Max plane, pushed out by the gap.
+int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const float* normals, double max_axis_scale,
+                          float plane_gap_inv, float* planes /* 8 floats per normal */)
+{
+    if (!points || !normals || !planes || n == 0) return SURTR_E_INVALID;
+    auto dot = [](const float* a, const float* b) { float t = a[0] * b[0] + a[1] * b[1]; return t + a[2] * b[2]; };
+    for (uint32_t j = 0; j < k; ++j)
+    {
+        const float* nr = normals + 3 * j;
+        double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
+        uint32_t vlo = 0, vhi = 0;
+        for (uint32_t v = 0; v < n; ++v)
+        {
+            const float t = dot(points + 3 * v, nr);
+            if (lo > t) { lo = t; vlo = v; }
+            if (hi < t) { hi = t; vhi = v; }
+        }
+        const float gap = (float)(max_axis_scale / plane_gap_inv);
+        for (int side = 0; side < 2; ++side)
+        {
+            float nn[3] = {side ? nr[0] : -nr[0], side ? nr[1] : -nr[1], side ? nr[2] : -nr[2]};
+            float t = nn[0] * nn[0] + nn[1] * nn[1]; t = t + nn[2] * nn[2];
+            const float len = std::sqrt(t);
+            if (len != 0.f) { nn[0] = nn[0] / len; nn[1] = nn[1] / len; nn[2] = nn[2] / len; } else { nn[0] = nn[1] = nn[2] = 0.f; }
+            const float* pv = points + 3 * (size_t)(side ? vhi : vlo);
+            const float q[3] = {pv[0] + nn[0] * gap, pv[1] + nn[1] * gap, pv[2] + nn[2] * gap};
+            float* out = planes + 8 * (size_t)j + 4 * side;
+            out[0] = nn[0]; out[1] = nn[1]; out[2] = nn[2]; out[3] = -dot(q, nn);
+        }
+    }
     return SURTR_OK;
 }
 

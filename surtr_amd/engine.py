@@ -333,3 +333,28 @@ def merge_fragments(parts):
 def cell_block(rank, world, n_cells):
     """Contiguous cell block of a rank: [floor(r*C/G), floor((r+1)*C/G))."""
     return (rank * n_cells) // world, ((rank + 1) * n_cells) // world
+
+
+def hull_normals(points, limit):
+    """VMACH::ConvexHull(points, limit) face normals (host helper)."""
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    cnt = ctypes.c_uint32()
+    rc = lib().surtr_hull_normals(ctypes.c_uint32(p.shape[0]), _p(p), ctypes.c_uint32(limit), ctypes.c_uint32(0), None, ctypes.byref(cnt))
+    if rc:
+        raise SurtrError(rc)
+    out = np.zeros((cnt.value, 3), np.float32)
+    rc = lib().surtr_hull_normals(ctypes.c_uint32(p.shape[0]), _p(p), ctypes.c_uint32(limit), ctypes.c_uint32(cnt.value), _p(out), ctypes.byref(cnt))
+    if rc:
+        raise SurtrError(rc)
+    return out
+
+
+def kdop_ach_planes(points, normals, max_axis_scale, plane_gap_inv=2000.0):
+    p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+    n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+    out = np.zeros((2 * n.shape[0], 4), np.float32)
+    rc = lib().surtr_kdop_ach_planes(ctypes.c_uint32(p.shape[0]), _p(p), ctypes.c_uint32(n.shape[0]), _p(n), ctypes.c_double(max_axis_scale),
+                                     ctypes.c_float(plane_gap_inv), _p(out))
+    if rc:
+        raise SurtrError(rc)
+    return out

@@ -119,3 +119,20 @@ def refracture_scene(meshes, convexes, cells_per_piece, seed=SEED):
     return {"face_off": np.concatenate(face_off), "v012": np.concatenate(v012), "scales": np.array(scales, np.float32),
             "shifts": np.array(shifts, np.float32), "group_cell_off": np.arange(0, base_cell + 1, cells_per_piece, dtype=np.uint32),
             "pair_cell": np.array(pair_cell, np.uint32), "pair_piece": np.array(pair_piece, np.uint32), "n_cells": base_cell}
+
+
+ICH_POINT_LIMIT = 20       # FractureArgs::ICHIncludePointLimit, Inc/Surtr.h:89-110
+ACH_PLANE_GAP_INV = 2000.0  # FractureArgs::ACHPlaneGapInverse
+
+
+def ach_convex(eng, verts):
+    """PrepareFracture steps 1-6 (Src/Surtr.cpp:1750-1785): ICH(20) face normals -> k-DOP slabs pushed out by
+    MaxAxisScale/2000 -> the 2x bounding box clipped by all of them (on the GPU, through surtr_clip_polyhedron)."""
+    v = np.ascontiguousarray(verts, np.float32)
+    lo, hi = v.min(0), v.max(0)
+    extent = (hi - lo).astype(np.float32)
+    center = ((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32)
+    normals = engine.hull_normals(v, ICH_POINT_LIMIT)
+    max_axis = float(max(float(hi[0]) - float(lo[0]), float(hi[1]) - float(lo[1]), float(hi[2]) - float(lo[2])))
+    planes = engine.kdop_ach_planes(v, normals, max_axis, ACH_PLANE_GAP_INV)
+    return eng.clip_polyhedron(box_solid(extent, center), planes), planes

@@ -177,3 +177,34 @@ def test_wide_global_variant(emul_engine_small, oracle, which):
     c, got, ref = run_event(emul_engine_small, oracle, sc, 3, cells=cells)
     assert_event_equal(got, ref)
     assert np.array_equal(got["mesh_pos"], ref["mesh_pos"])
+
+
+def test_ach_convex_matches_oracle(emul_engine, oracle):
+    """PrepareFracture steps 1-6: limited hull normals, k-DOP planes (host helpers) and the GPU clip of the 2x box."""
+    from surtr_amd import meshgen, engine
+    for v, t in (meshgen.cube(), meshgen.blob(scale=70.0), meshgen.bumpy_torus(60, 40)):
+        for limit in (4, 9, 20):
+            assert np.array_equal(engine.hull_normals(v, limit), oracle.hull_normals(v, limit))
+        eng = emul_engine.Engine(0)
+        conv, planes = scenes.ach_convex(eng, v)
+        eng.close()
+        ext = v.max(0) - v.min(0)
+        cen = ((v.max(0).astype(np.float64) + v.min(0).astype(np.float64)) / 2.0).astype(np.float32)
+        n = oracle.hull_normals(v, 20)
+        pl = oracle.kdop_planes(v, n, ach=True, max_axis_scale=float(ext.max()), gap_inv=2000.0)
+        assert np.array_equal(planes, pl)
+        ref = oracle.clip(scenes.box_solid(ext, cen), pl)
+        assert np.array_equal(conv["off"], ref["off"]) and np.array_equal(conv["nbr"], ref["nbr"])
+        assert np.array_equal(conv["pos"], ref["pos"])
+        assert conv["pos"].shape[0] >= 8
+
+
+def test_event_with_ach_convex(emul_engine, oracle):
+    from surtr_amd import meshgen
+    v, t = meshgen.blob(scale=70.0)
+    sc = scenes.make_scene(v, t, 64)
+    eng = emul_engine.Engine(0)
+    sc["convex"], _ = scenes.ach_convex(eng, v)
+    eng.close()
+    c, got, ref = run_event(emul_engine, oracle, sc, 3, cells=48)
+    assert_event_equal(got, ref)

@@ -195,3 +195,16 @@ def test_cpp_host_layer_and_harness(gpu_engine, oracle):
     ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, threads=8)
     assert out["fragments"] == ref["frag_ids"].shape[0] and out["mesh_verts"] == ref["mesh_pos"].shape[0]
     assert out["indices"] == ref["idx"].shape[0] and out["mesh_nbrs"] == ref["mesh_nbr"].shape[0]
+
+
+def test_torus_with_ach_convex(gpu_engine, oracle):
+    """cfg4 with the reference's initial Convex (ACH: ICH(20) normals -> k-DOP -> clipped 2x box) instead of the plain box."""
+    sc = scenes.torus_scene(4096)
+    eng = gpu_engine.Engine(0)
+    sc["convex"], planes = scenes.ach_convex(eng, sc["mesh"]["pos"])
+    eng.close()
+    n = oracle.hull_normals(sc["mesh"]["pos"], 20)
+    assert planes.shape[0] == 2 * n.shape[0] and sc["convex"]["pos"].shape[0] > 8
+    c, got, ref = run_event(gpu_engine, oracle, sc, 3, threads=16)
+    assert c.status == 0
+    assert_event_equal(got, ref)
