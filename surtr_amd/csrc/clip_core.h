@@ -38,7 +38,7 @@
 #ifndef SURTR_WG
 #define SURTR_WG 256
 #endif
-#define SURTR_NWAVE (SURTR_WG / 64)
+#define SURTR_NWAVE (SURTR_WG / 64)   // the LARGEST group a kernel is launched with; smaller launches use fewer
 #endif
 #include <stdint.h>
 #ifdef SURTR_EMUL
@@ -162,6 +162,9 @@ __device__ __forceinline__ int side_of(float s)
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (SURTR_LANES - 1u); }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> SURTR_LSH; }
+// Size of the launched group and its wave count (kernels for small solids run one wave per task).
+__device__ __forceinline__ uint32_t group_size() { return blockDim.x; }
+__device__ __forceinline__ uint32_t group_waves() { return blockDim.x >> SURTR_LSH; }
 
 __device__ __forceinline__ uint2 wave_incl_scan2(uint2 v)
 {
@@ -187,7 +190,7 @@ __device__ inline void scan_block_array(uint32_t nb, uint2* blk, Shared& sh, uin
 {
     const uint32_t l = lane_id(), w = wave_id();
     uint2 carry = make_uint2(0u, 0u);
-    for (uint32_t c0 = 0; c0 < nb; c0 += SURTR_WG)
+    for (uint32_t c0 = 0; c0 < nb; c0 += group_size())
     {
         const uint32_t i = c0 + threadIdx.x;
         uint2 x = make_uint2(0u, 0u);
@@ -196,8 +199,7 @@ __device__ inline void scan_block_array(uint32_t nb, uint2* blk, Shared& sh, uin
         if (l == SURTR_LANES - 1u) { sh.wsum[2 * w] = inc.x; sh.wsum[2 * w + 1] = inc.y; }
         __syncthreads();
         uint2 woff = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
-#pragma unroll
-        for (uint32_t q = 0; q < SURTR_NWAVE; ++q)
+        for (uint32_t q = 0; q < group_waves(); ++q)
         {
             const uint32_t a = sh.wsum[2 * q], bq = sh.wsum[2 * q + 1];
             if (q < w) { woff.x += a; woff.y += bq; }
@@ -218,7 +220,7 @@ __device__ void scan_blocks(uint32_t n, uint2* blk, Shared& sh, Fn fn, uint32_t&
 {
     const uint32_t nb = (n + SURTR_LANES - 1u) >> SURTR_LSH;
     const uint32_t l = lane_id(), w = wave_id();
-    for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = w; b < nb; b += group_waves())
     {
         const uint32_t i = (b << SURTR_LSH) + l;
         uint2 c = make_uint2(0u, 0u);
@@ -364,7 +366,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
     STAMP_DECL;
-    for (uint32_t k = tid; k <= SURTR_MAXF; k += SURTR_WG)
+    for (uint32_t k = tid; k <= SURTR_MAXF; k += group_size())
     {
         sh.hist[k] = 0; sh.zhist[k] = 0;
         if (k < F)
@@ -384,7 +386,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
-    for (uint32_t b0 = w; b0 < nbV; b0 += 4u * SURTR_NWAVE)
+    for (uint32_t b0 = w; b0 < nbV; b0 += 4u * group_waves())
     {
         // four 64-blocks per wave iteration: their loads are in flight together, and every plane fetched
         // from LDS is applied to all four (planes outermost: one LDS fetch per plane, four independent chains)
@@ -393,7 +395,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
 #pragma unroll
         for (int g = 0; g < 4; ++g)
         {
-            const uint32_t v = ((b0 + g * SURTR_NWAVE) << SURTR_LSH) + l;
+            const uint32_t v = ((b0 + g * group_waves()) << SURTR_LSH) + l;
             valid4[g] = v < V;
             const uint32_t vv = valid4[g] ? v : 0u;
             px4[g] = in.pos[3 * vv]; py4[g] = in.pos[3 * vv + 1]; pz4[g] = in.pos[3 * vv + 2];
@@ -428,7 +430,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
 #pragma unroll
         for (int g = 0; g < 4; ++g)
         {
-            const uint32_t b = b0 + g * SURTR_NWAVE;
+            const uint32_t b = b0 + g * group_waves();
             if (b >= nbV) break;
             const uint32_t v = (b << SURTR_LSH) + l;
             const uint32_t f = f4[g];
@@ -455,7 +457,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     STAMP(0);
     // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
     const uint32_t nNeedy = sh.misc[3];
-    for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += SURTR_WG)
+    for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += group_size())
     {
         const uint32_t i = i0 + l;
         bool keep = false, drop = false, zero = false; uint32_t f = 0, v = 0;
@@ -525,7 +527,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     // ---- A3: per 64-block (kept vertices, their ring entries) ----
     {
         bool toolong = false;
-        for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
+        for (uint32_t b = w; b < nbV; b += group_waves())
         {
             const unsigned long long m = bmask[b];
             uint2 inc = make_uint2(0u, 0u);
@@ -551,7 +553,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
         // a global copy of the bit mask always exists (clip_planes' all-in-plane corner case reads it).  The LDS
         // masks share the tail of the ring area; a band that needs all of it moves both mask arrays to global scratch.
         const bool spill = hsum > capH_emit && hsum <= T.capH;
-        for (uint32_t b = tid; b < nbV; b += SURTR_WG) { spill_mask[b] = bmask[b]; if (spill) spill_blk[b] = bblk[b]; }
+        for (uint32_t b = tid; b < nbV; b += group_size()) { spill_mask[b] = bmask[b]; if (spill) spill_blk[b] = bblk[b]; }
         __syncthreads();
         if (spill) { bmask = spill_mask; bblk = spill_blk; capH_emit = T.capH; }
     }
@@ -560,7 +562,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     if (hsum > capH_emit) COUNT(34);
     if (toolong || n > T.capV || hsum > capH_emit || n >= TT::SENT) return SURTR_OVERFLOW;
     // ---- emit: slot table first (sparse sweep, no gathers), then rings densely over the kept vertices ----
-    for (uint32_t b = w; b < nbV; b += SURTR_NWAVE)
+    for (uint32_t b = w; b < nbV; b += group_waves())
     {
         const unsigned long long m = bmask[b];
         if (m == 0ull) continue;
@@ -584,7 +586,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
         if (!((m >> bit) & 1ull)) return TT::SENT;
         return bblk[(uint32_t)u >> SURTR_LSH].x + (uint32_t)__builtin_popcountll(m & ((1ull << bit) - 1ull));
     };
-    for (uint32_t id = tid; id < n; id += SURTR_WG)
+    for (uint32_t id = tid; id < n; id += group_size())
     {
         const uint32_t v = orig[id];
         T.pos[3 * id] = in.pos[3 * v]; T.pos[3 * id + 1] = in.pos[3 * v + 1]; T.pos[3 * id + 2] = in.pos[3 * v + 2];
@@ -634,7 +636,7 @@ __device__ void squeeze(Topo<TT>& T, Shared& sh, const SqueezeTmp tmp)
     scan_blocks(T.nS, T.blk, sh, livefn, nn, hh);
     const uint32_t nb = (T.nS + SURTR_LANES - 1u) >> SURTR_LSH;
     uint32_t* idmap = T.aux0;
-    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = wave_id(); b < nb; b += group_waves())
     {
         const uint32_t v = (b << SURTR_LSH) + lane_id();
         uint2 c = make_uint2(0u, 0u);
@@ -649,7 +651,7 @@ __device__ void squeeze(Topo<TT>& T, Shared& sh, const SqueezeTmp tmp)
         }
     }
     __syncthreads();
-    for (uint32_t v = threadIdx.x; v < T.nS; v += SURTR_WG)
+    for (uint32_t v = threadIdx.x; v < T.nS; v += group_size())
     {
         if (T.comp[v] == SURTR_DEAD) continue;
         const I* r = T.ring + T.loff[v];
@@ -658,12 +660,12 @@ __device__ void squeeze(Topo<TT>& T, Shared& sh, const SqueezeTmp tmp)
         for (uint32_t q = 0; q < len; ++q) { const uint32_t u = r[q]; d[q] = u >= TT::SENT ? u : idmap[u]; }
     }
     __syncthreads();
-    for (uint32_t v = threadIdx.x; v < nn; v += SURTR_WG)
+    for (uint32_t v = threadIdx.x; v < nn; v += group_size())
     {
         T.pos[3 * v] = tmp.pos[3 * v]; T.pos[3 * v + 1] = tmp.pos[3 * v + 1]; T.pos[3 * v + 2] = tmp.pos[3 * v + 2];
         T.loff[v] = (typename TT::off_t)tmp.loff[v]; T.llen[v] = (typename TT::len_t)tmp.llen[v]; T.comp[v] = tmp.comp[v];
     }
-    for (uint32_t e = threadIdx.x; e < hh; e += SURTR_WG) T.ring[e] = (I)tmp.ring[e];
+    for (uint32_t e = threadIdx.x; e < hh; e += group_size()) T.ring[e] = (I)tmp.ring[e];
     T.nS = nn; T.hUsed = hh;
     __syncthreads();
 }
@@ -681,7 +683,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
     if (T.nLive == 0) return 0;
     bool squeezed = false;
     uint32_t it = 0;
-    for (uint32_t q = tid; q < 24; q += SURTR_WG) (&sh.pf[0][0])[q] = 0;
+    for (uint32_t q = tid; q < 24; q += group_size()) (&sh.pf[0][0])[q] = 0;
     __syncthreads();
     for (uint32_t k = 0; k < F; ++k)
     {
@@ -694,7 +696,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         // ---- classify (:307-318) ----
         {
             bool anyc = false, anyk = false, anyz = false;
-            for (uint32_t v = tid; v < nS; v += SURTR_WG)
+            for (uint32_t v = tid; v < nS; v += group_size())
             {
                 if (T.comp[v] == SURTR_DEAD) continue;
                 const int c = side_of(plane_dist(pl, T.pos[3 * v], T.pos[3 * v + 1], T.pos[3 * v + 2]));
@@ -804,7 +806,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // sparse sweep (LDS only): which (clipped vertex, slot) makes new vertex n0 + t, in reference order
             uint32_t* srcv = T.succ; uint32_t* srcj = T.pred;
             const uint32_t nb = (n0 + SURTR_LANES - 1u) >> SURTR_LSH;
-            for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
+            for (uint32_t b = w; b < nb; b += group_waves())
             {
                 // blocks that produce no new vertex (most of them) are skipped without touching memory
                 const uint32_t first = T.blk[b].x, beyond = (b + 1u < nb) ? T.blk[b + 1u].x : M;
@@ -830,7 +832,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
             uint32_t* keptof = T.aux1;     // kept end of every new vertex, for the back-link patch below
             bool dup = false;
-            for (uint32_t t = tid; t < M; t += SURTR_WG)
+            for (uint32_t t = tid; t < M; t += group_size())
             {
                 const uint32_t v = srcv[t], j = srcj[t], fresh = n0 + t;
                 I* r = T.ring + T.loff[v];
@@ -859,7 +861,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // links of the two ends (:350-354): "find the clipped vertex in the kept vertex's ring, overwrite it"
             if (!ordered)
             {
-                for (uint32_t t = tid; t < M; t += SURTR_WG)
+                for (uint32_t t = tid; t < M; t += group_size())
                 {
                     const uint32_t v = srcv[t], u = keptof[t], fresh = n0 + t;
                     I* ru = T.ring + T.loff[u];
@@ -892,7 +894,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // regular cap: every new vertex X=[cut, kept] finds its successor by walking the face
             // loop through clipped vertices; its final ring is [pred, succ, kept].
             bool bad = false;
-            for (uint32_t t = tid; t < M; t += SURTR_WG)
+            for (uint32_t t = tid; t < M; t += group_size())
             {
                 const uint32_t X = n0 + t;
                 uint32_t prev = X, c = T.ring[T.loff[X]], steps = 0;
@@ -916,16 +918,16 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             if (bad) pf[4] = 1;
             __syncthreads();
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-            if (tid == 0) { atomicAdd(&g_stamp[42], (unsigned long long)sh.misc[5]); atomicAdd(&g_stamp[43], 1ull); atomicAdd(&g_stamp[44], (unsigned long long)((M + SURTR_WG - 1) / SURTR_WG)); sh.misc[5] = 0; }
+            if (tid == 0) { atomicAdd(&g_stamp[42], (unsigned long long)sh.misc[5]); atomicAdd(&g_stamp[43], 1ull); atomicAdd(&g_stamp[44], (unsigned long long)((M + group_size() - 1) / group_size())); sh.misc[5] = 0; }
 #endif
             bad = false;
-            for (uint32_t t = tid; t < M; t += SURTR_WG) if (T.pcnt[t] != 1u) bad = true;
+            for (uint32_t t = tid; t < M; t += group_size()) if (T.pcnt[t] != 1u) bad = true;
             if (bad) pf[4] = 1;
             __syncthreads();
             serial = pf[4] != 0;
             if (!serial)
             {
-                for (uint32_t t = tid; t < M; t += SURTR_WG)
+                for (uint32_t t = tid; t < M; t += group_size())
                 {
                     const uint32_t lo = T.loff[n0 + t];
                     const I kept = T.ring[lo + 1];
@@ -941,9 +943,9 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // receives (:404-421).  Walks only traverse rings of clipped vertices, which the relink never modifies,
             // so their targets do not depend on the processing order.
             uint32_t* snapoff = T.aux0; uint32_t* cap = T.aux1; uint32_t* zlist = T.aux2; uint32_t* arrive = T.pcnt;
-            for (uint32_t v = tid; v < n1; v += SURTR_WG) arrive[v] = 0;
+            for (uint32_t v = tid; v < n1; v += group_size()) arrive[v] = 0;
             __syncthreads();
-            for (uint32_t v = tid; v < n1; v += SURTR_WG)
+            for (uint32_t v = tid; v < n1; v += group_size())
             {
                 const int cv = T.comp[v];
                 if (!(cv == 0 || cv == 2)) continue;
@@ -977,7 +979,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             if (hend + zw > T.capH) { COUNT(37); return SURTR_OVERFLOW; }
             const uint32_t nb = (n1 + SURTR_LANES - 1u) >> SURTR_LSH;
             bool toolong = false;
-            for (uint32_t b = w; b < nb; b += SURTR_NWAVE)
+            for (uint32_t b = w; b < nb; b += group_waves())
             {
                 const uint32_t v = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
@@ -1012,7 +1014,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             __syncthreads();
             {
                 bool two = false;
-                for (uint32_t v = tid; v < n1; v += SURTR_WG)
+                for (uint32_t v = tid; v < n1; v += group_size())
                 {
                     if (T.comp[v] == SURTR_DEAD) continue;
                     I* r = T.ring + T.loff[v];
@@ -1036,7 +1038,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         // ---- tombstones instead of the per-plane compaction (:464-495); live count for :497-499 ----
         {
             uint32_t live = 0; bool dangling = false;
-            for (uint32_t v = tid; v < n1; v += SURTR_WG)
+            for (uint32_t v = tid; v < n1; v += group_size())
             {
                 const int c = T.comp[v];
                 if (c == SURTR_DEAD) continue;
@@ -1058,7 +1060,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         if (sh.flagErr) return 2;
         if (serial)
         {
-            for (uint32_t v = tid; v < n1; v += SURTR_WG) if (T.comp[v] < 0) T.comp[v] = SURTR_DEAD;
+            for (uint32_t v = tid; v < n1; v += group_size()) if (T.comp[v] < 0) T.comp[v] = SURTR_DEAD;
             __syncthreads();
         }
         T.nS = n1; T.hUsed = hend; T.nLive = pf[5];
@@ -1079,7 +1081,7 @@ __device__ uint2 index_live(Topo<TT>& T, Shared& sh)
     uint32_t nn = 0, hh = 0;
     scan_blocks(T.nS, T.blk, sh, livefn, nn, hh);
     const uint32_t nb = (T.nS + SURTR_LANES - 1u) >> SURTR_LSH;
-    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = wave_id(); b < nb; b += group_waves())
     {
         const uint32_t v = (b << SURTR_LSH) + lane_id();
         uint2 c = make_uint2(0u, 0u);
@@ -1096,7 +1098,7 @@ template <class TT>
 __device__ void write_solid(const Topo<TT>& T, float* dpos, uint32_t* dloff, uint32_t* dllen, int32_t* dnbr, uint32_t voff,
                             uint32_t hoff)
 {
-    for (uint32_t v = threadIdx.x; v < T.nS; v += SURTR_WG)
+    for (uint32_t v = threadIdx.x; v < T.nS; v += group_size())
     {
         if (T.comp[v] == SURTR_DEAD) continue;
         const uint32_t id = voff + T.aux0[v];

@@ -113,20 +113,28 @@ static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX)
 }
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
-struct LdsTopo
+template <uint32_t LV, uint32_t LH>
+struct LdsTopoT
 {
-    uint16_t loff[SURTR_LV];
-    uint8_t llen[SURTR_LV];
-    int8_t comp[SURTR_LV];
-    uint2 blk[SURTR_LV / SURTR_LANES + 2];
+    static constexpr uint32_t kLV = LV, kLH = LH;
+    uint16_t loff[LV];
+    uint8_t llen[LV];
+    int8_t comp[LV];
+    uint2 blk[LV / SURTR_LANES + 2];
     unsigned long long align_;
-    uint16_t ring[SURTR_LH];
+    uint16_t ring[LH];
 };
+typedef LdsTopoT<SURTR_LV, SURTR_LH> LdsTopo;          // Mesh solids: two workgroups of 256 threads per CU
+#ifdef SURTR_EMUL
+typedef LdsTopoT<64, 512> LdsTopoSmall;                 // (emulation: small enough to exercise the fallback too)
+#else
+typedef LdsTopoT<512, 4096> LdsTopoSmall;               // Convex solids: one wave per task, many tasks per CU
+#endif
 
 // Clips `in` by sh.planes[0..F) and hands the resulting Topo (nLive == 0: empty) to `consume`.
 // Returns 0 or an error code (uniform over the workgroup).
-template <class Consume>
-__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LdsTopo& L, Consume consume)
+template <class LT, class Consume>
+__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume)
 {
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
     int rc;
@@ -134,17 +142,17 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
         Topo<InLds> T;
         T.loff = L.loff; T.llen = L.llen; T.comp = L.comp; T.ring = L.ring; T.pos = S.pos;
         T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = L.blk;
-        T.capV = SURTR_LV < S.CV ? SURTR_LV : S.CV; T.capH = SURTR_LH;
+        T.capV = LT::kLV < S.CV ? LT::kLV : S.CV; T.capH = LT::kLH;
         T.nS = T.nLive = T.hUsed = 0;
         // pre-pass masks sit in the tail of the ring area while the reduced solid is being emitted
         // (the tail is free again afterwards); a copy of the bit mask goes to global scratch for the
         // all-in-plane corner case of clip_planes
-        unsigned long long* bmask = S.gmask; uint2* bblk = S.gblk; uint32_t capEmit = SURTR_LH;
-        if ((size_t)nbV * 8u <= SURTR_LH / 2u)
+        unsigned long long* bmask = S.gmask; uint2* bblk = S.gblk; uint32_t capEmit = LT::kLH;
+        if ((size_t)nbV * 8u <= LT::kLH / 2u)
         {
-            bblk = (uint2*)(L.ring + SURTR_LH) - nbV;
+            bblk = (uint2*)(L.ring + LT::kLH) - nbV;
             bmask = (unsigned long long*)bblk - nbV;
-            capEmit = SURTR_LH - nbV * 8u;
+            capEmit = LT::kLH - nbV * 8u;
         }
         rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
         if (rc == 0)
@@ -265,14 +273,14 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
     const uint32_t tid = threadIdx.x, nS = T.nS;
     const uint2 tot = index_live(T, sh);              // aux0 = packed index, aux2 = packed ring offset
     uint32_t* lab = T.aux1;
-    for (uint32_t v = tid; v < nS; v += SURTR_WG) lab[v] = v;
+    for (uint32_t v = tid; v < nS; v += group_size()) lab[v] = v;
     __syncthreads();
     while (true)
     {
         if (tid == 0) sh.changed = 0;
         __syncthreads();
         bool ch = false;
-        for (uint32_t v = tid; v < nS; v += SURTR_WG)
+        for (uint32_t v = tid; v < nS; v += group_size())
         {
             if (T.comp[v] == SURTR_DEAD) continue;
             uint32_t m = lab[v];
@@ -304,7 +312,7 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
         // island index of a root = its rank among roots (discovery order = lowest vertex first)
         uint32_t* irank = T.aux2; uint32_t* local = T.aux0;
         const uint32_t nb = (nS + SURTR_LANES - 1u) >> SURTR_LSH;
-        for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+        for (uint32_t b = wave_id(); b < nb; b += group_waves())
         {
             const uint32_t v = (b << SURTR_LSH) + lane_id();
             uint2 c = make_uint2(0u, 0u);
@@ -321,7 +329,7 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
             };
             uint32_t tv = 0, th = 0;
             scan_blocks(nS, T.blk, sh, isfn, tv, th);
-            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            for (uint32_t b = wave_id(); b < nb; b += group_waves())
             {
                 const uint32_t v = (b << SURTR_LSH) + lane_id();
                 uint2 c = make_uint2(0u, 0u);
@@ -340,7 +348,7 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
             }
             if (tid == 0) A.isl[ioff + t] = make_uint2(tv, th);
             __syncthreads();
-            for (uint32_t v = tid; v < nS; v += SURTR_WG)
+            for (uint32_t v = tid; v < nS; v += group_size())
             {
                 if (T.comp[v] == SURTR_DEAD || irank[lab[v]] != t) continue;
                 const uint32_t dv = voff + vbase + local[v];
@@ -358,13 +366,58 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
     return 0;
 }
 
+// ------------------------------------------------------------- k_clip_convex
+// Convex of every (cell, piece) pair first (Src/Surtr.cpp:1466-1468): small solids, one wave per task.
+__global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const float4* __restrict__ planes,
+                                                    const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                    uint32_t n_pairs, const uint8_t* __restrict__ outside,
+                                                    ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
+                                                    const uint2* __restrict__ pair_list)
+{
+    __shared__ Shared sh;
+    __shared__ LdsTopoSmall L;
+    Scratch S = carve(pool, blockIdx.x);
+    const uint32_t tid = threadIdx.x;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[8], 1u);
+        __syncthreads();
+        const uint32_t p = sh.misc[7];
+        if (p >= n_pairs) break;
+        const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
+        const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
+        PairRec rec;
+        memset(&rec, 0, sizeof(rec));
+        bool skip = outside != nullptr && outside[piece] != 0;
+        const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
+        if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
+        int err = 0;
+        if (!skip)
+        {
+            for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
+            __syncthreads();
+            const uint32_t c0 = P.cvo[piece];
+            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0};
+            err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
+                if (T.nLive == 0) return 0;
+                return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
+            });
+            __syncthreads();
+        }
+        if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+        if (tid == 0) pairs[p] = rec;
+    }
+}
+
 // -------------------------------------------------------------- k_clip_pairs
+// Mesh of every pair whose Convex survived (:1470-1500): clip, islands, island-major copy to the arena.
 #ifndef SURTR_CLIP_MINWAVES
 #define SURTR_CLIP_MINWAVES 1
 #endif
 __global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
-                                                         uint32_t n_pairs, const uint8_t* __restrict__ outside,
+                                                         uint32_t n_pairs,
                                                          ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
                                                          const uint2* __restrict__ pair_list)
 {
@@ -382,42 +435,23 @@ __global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pi
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
+        PairRec rec = pairs[p];
+        if (rec.cv_n == 0 || rec.status != 0) continue;       // empty Convex: the Mesh is not clipped (:1467-1468)
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
         const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
-        PairRec rec;
-        memset(&rec, 0, sizeof(rec));
-        bool skip = outside != nullptr && outside[piece] != 0;
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
-        if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
-        int err = 0;
-        if (!skip)
-        {
-            for (uint32_t k = tid; k < F; k += SURTR_WG) sh.planes[k] = planes[f0 + k];
-            __syncthreads();
-            // Convex first (Src/Surtr.cpp:1466-1468); an empty Convex skips the Mesh
-            const uint32_t c0 = P.cvo[piece];
-            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0};
-            bool have_convex = false;
-            err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
-                if (T.nLive == 0) return 0;
-                have_convex = true;
-                return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
-            });
-            __syncthreads();
-            if (err == 0 && have_convex)
-            {
-                const uint32_t m0 = P.mvo[piece];
-                SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0};
-                err = clip_any(min, F, S, sh, L, [&](auto& T) -> int {
-                    if (T.nLive == 0) return 0;
-                    return park_mesh_islands(T, sh, A, rec);
-                });
-                __syncthreads();
-            }
-        }
+        for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
+        __syncthreads();
+        const uint32_t m0 = P.mvo[piece];
+        SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0};
+        int err = clip_any(min, F, S, sh, L, [&](auto& T) -> int {
+            if (T.nLive == 0) return 0;
+            return park_mesh_islands(T, sh, A, rec);
+        });
+        __syncthreads();
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -444,7 +478,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restri
     const uint32_t nb = (n_pairs + SURTR_LANES - 1u) >> SURTR_LSH;
     if (nf <= cap_frags)
     {
-        for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+        for (uint32_t b = wave_id(); b < nb; b += group_waves())
         {
             const uint32_t p = (b << SURTR_LSH) + lane_id();
             uint2 c = make_uint2(0u, 0u);
@@ -498,7 +532,7 @@ __device__ static A wg_argmax(A mine, A* slots /* shared, SURTR_NWAVE */)
     if (lane_id() == 0) slots[wave_id()] = mine;
     __syncthreads();
     A best = slots[0];
-    for (uint32_t q = 1; q < SURTR_NWAVE; ++q)
+    for (uint32_t q = 1; q < group_waves(); ++q)
     {
         const A o = slots[q];
         if (o.i != 0xFFFFFFFFu && (best.i == 0xFFFFFFFFu || o.v > best.v || (o.v == best.v && o.i < best.i))) best = o;
@@ -516,7 +550,7 @@ __device__ __forceinline__ float hull_vol(const float* a, const float* b, const 
     return ax * (by * cz - bz * cy) + ay * (bz * cx - bx * cz) + az * (bx * cy - by * cx);
 }
 
-__global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
+__global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     ScratchPool pool, Arena A)
 {
     __shared__ Shared sh;
@@ -525,7 +559,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
     __shared__ float hp[4][3];
     __shared__ float nrm[4][3];
     __shared__ ArgF kmin[4][SURTR_NWAVE], kmax[4][SURTR_NWAVE];
-    __shared__ LdsTopo L;
+    __shared__ LdsTopoSmall L;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
@@ -541,7 +575,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
         const uint32_t n = fr.mv_n;
         // ---- BuildFirstHull (Src/VMACH.cpp:1036-1085) with limit min(n,4) = 4 ----
         ArgF a; a.i = 0xFFFFFFFFu; a.v = 0.f;
-        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        for (uint32_t v = tid; v < n; v += group_size())
         {
             const float x = mp[3 * v];
             if (a.i == 0xFFFFFFFFu || x > a.v) { a.v = x; a.i = v; }
@@ -550,7 +584,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
         const uint32_t i1 = a.i;
         const float p1x = mp[3 * i1], p1y = mp[3 * i1 + 1], p1z = mp[3 * i1 + 2];
         ArgD d; d.i = 0xFFFFFFFFu; d.v = 0.0;
-        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        for (uint32_t v = tid; v < n; v += group_size())
         {
             const double dx = (double)(mp[3 * v] - p1x), dy = (double)(mp[3 * v + 1] - p1y), dz = (double)(mp[3 * v + 2] - p1z);
             const double dist = sqrt(dx * dx + dy * dy + dz * dz);
@@ -560,7 +594,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
         const uint32_t i2 = d.i;
         const float p2x = mp[3 * i2], p2y = mp[3 * i2 + 1], p2z = mp[3 * i2 + 2];
         a.i = 0xFFFFFFFFu; a.v = 0.f;
-        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        for (uint32_t v = tid; v < n; v += group_size())
         {
             // ConvexHullFace(v1, v2, p).CalcArea(): 0.5 * |(v2-v1) x (p-v1)|
             const float ux = p2x - p1x, uy = p2y - p1y, uz = p2z - p1z;
@@ -574,7 +608,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
         const float q1[3] = {p1x, p1y, p1z}, q2[3] = {p2x, p2y, p2z};
         const float q3[3] = {mp[3 * i3], mp[3 * i3 + 1], mp[3 * i3 + 2]};
         a.i = 0xFFFFFFFFu; a.v = 0.f;
-        for (uint32_t v = tid; v < n; v += SURTR_WG)
+        for (uint32_t v = tid; v < n; v += group_size())
         {
             const float vol = hull_vol(q1, q2, q3, mp + 3 * v);
             if (a.i == 0xFFFFFFFFu || vol > a.v) { a.v = vol; a.i = v; }
@@ -606,7 +640,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_refit(FragRec* __restrict__ frags,
         {
             ArgF lo, hi; lo.i = hi.i = 0xFFFFFFFFu; lo.v = hi.v = 0.f;
             const float nx = nrm[k][0], ny = nrm[k][1], nz = nrm[k][2];
-            for (uint32_t v = tid; v < n; v += SURTR_WG)
+            for (uint32_t v = tid; v < n; v += group_size())
             {
                 const float t = dot3(mp[3 * v], mp[3 * v + 1], mp[3 * v + 2], nx, ny, nz);
                 if (hi.i == 0xFFFFFFFFu || t > hi.v) { hi.v = t; hi.i = v; }
@@ -850,7 +884,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         __syncthreads();
         {
             bool dup = false;
-            for (uint32_t v = tid; v < n; v += SURTR_WG)
+            for (uint32_t v = tid; v < n; v += group_size())
             {
                 const uint32_t lo = loff[v] - fr.mh_off, len = llen[v];
                 for (uint32_t s = 0; s < len; ++s)
@@ -877,7 +911,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             int32_t* kc = keyA; int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
             for (uint32_t span = 1; span < H; span <<= 1)
             {
-                for (uint32_t e = tid; e < H; e += SURTR_WG)
+                for (uint32_t e = tid; e < H; e += group_size())
                 {
                     const int32_t t = xc[e];
                     const int32_t a = kc[e], b = kc[t];
@@ -910,7 +944,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
             if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
             const uint32_t nb = (H + SURTR_LANES - 1u) >> SURTR_LSH;
-            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            for (uint32_t b = wave_id(); b < nb; b += group_waves())
             {
                 const uint32_t e = (b << SURTR_LSH) + lane_id();
                 uint2 c = make_uint2(0u, 0u);
@@ -985,7 +1019,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
         //    room for 3*len indices at 3*lo
 #ifndef SURTR_EMUL
-        for (uint32_t fi = wave_id(); fi < nfaces; fi += SURTR_NWAVE)
+        for (uint32_t fi = wave_id(); fi < nfaces; fi += group_waves())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
             if (len < 5u || len > 64u) continue;
@@ -993,7 +1027,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             if (lane_id() == 0) fcnt[fi] = cnt;
         }
 #endif
-        for (uint32_t fi = tid; fi < nfaces; fi += SURTR_WG)
+        for (uint32_t fi = tid; fi < nfaces; fi += group_size())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
 #ifndef SURTR_EMUL
@@ -1013,7 +1047,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         if ((uint64_t)ioff + nidx > A.capI) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY); continue; }
         {
             const uint32_t nb = (nfaces + SURTR_LANES - 1u) >> SURTR_LSH;
-            for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+            for (uint32_t b = wave_id(); b < nb; b += group_waves())
             {
                 const uint32_t fi = (b << SURTR_LSH) + lane_id();
                 uint2 c = make_uint2(0u, 0u);
@@ -1041,7 +1075,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
     uint32_t t0 = 0, t1 = 0;
     auto f1 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].mv_n, frags[f].mh_n); };
     scan_blocks(nf, blk, sh, f1, t0, t1);
-    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = wave_id(); b < nb; b += group_waves())
     {
         const uint32_t f = (b << SURTR_LSH) + lane_id();
         uint2 c = make_uint2(0u, 0u);
@@ -1053,7 +1087,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
     __syncthreads();
     auto f2 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].cv_n, frags[f].ch_n); };
     scan_blocks(nf, blk, sh, f2, t0, t1);
-    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = wave_id(); b < nb; b += group_waves())
     {
         const uint32_t f = (b << SURTR_LSH) + lane_id();
         uint2 c = make_uint2(0u, 0u);
@@ -1065,7 +1099,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
     __syncthreads();
     auto f3 = [&](uint32_t f) -> uint2 { return make_uint2(frags[f].idx_n, 0u); };
     scan_blocks(nf, blk, sh, f3, t0, t1);
-    for (uint32_t b = wave_id(); b < nb; b += SURTR_NWAVE)
+    for (uint32_t b = wave_id(); b < nb; b += group_waves())
     {
         const uint32_t f = (b << SURTR_LSH) + lane_id();
         uint2 c = make_uint2(0u, 0u);
@@ -1141,30 +1175,30 @@ __global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ f
         }
         float* mpos = (float*)(blob + L.mpos) + 3 * (size_t)fr.o_mv;
         const float* sp = A.pos + 3 * (size_t)fr.mv_off;
-        for (uint32_t i = tid; i < 3 * fr.mv_n; i += SURTR_WG) mpos[i] = sp[i];
+        for (uint32_t i = tid; i < 3 * fr.mv_n; i += group_size()) mpos[i] = sp[i];
         uint32_t* mno = (uint32_t*)(blob + L.mno) + fr.o_mv;
-        for (uint32_t v = tid; v < fr.mv_n; v += SURTR_WG) mno[v] = fr.o_mh + (A.loff[fr.mv_off + v] - fr.mh_off);
+        for (uint32_t v = tid; v < fr.mv_n; v += group_size()) mno[v] = fr.o_mh + (A.loff[fr.mv_off + v] - fr.mh_off);
         int32_t* mnbr = (int32_t*)(blob + L.mnbr) + fr.o_mh;
-        for (uint32_t e = tid; e < fr.mh_n; e += SURTR_WG) mnbr[e] = A.nbr[fr.mh_off + e];
+        for (uint32_t e = tid; e < fr.mh_n; e += group_size()) mnbr[e] = A.nbr[fr.mh_off + e];
         float* cpos = (float*)(blob + L.cpos) + 3 * (size_t)fr.o_cv;
         const float* scp = A.pos + 3 * (size_t)fr.cv_off;
-        for (uint32_t i = tid; i < 3 * fr.cv_n; i += SURTR_WG) cpos[i] = scp[i];
+        for (uint32_t i = tid; i < 3 * fr.cv_n; i += group_size()) cpos[i] = scp[i];
         uint32_t* cno = (uint32_t*)(blob + L.cno) + fr.o_cv;
-        for (uint32_t v = tid; v < fr.cv_n; v += SURTR_WG) cno[v] = fr.o_ch + (A.loff[fr.cv_off + v] - fr.ch_off);
+        for (uint32_t v = tid; v < fr.cv_n; v += group_size()) cno[v] = fr.o_ch + (A.loff[fr.cv_off + v] - fr.ch_off);
         int32_t* cnbr = (int32_t*)(blob + L.cnbr) + fr.o_ch;
-        for (uint32_t e = tid; e < fr.ch_n; e += SURTR_WG) cnbr[e] = A.nbr[fr.ch_off + e];
+        for (uint32_t e = tid; e < fr.ch_n; e += group_size()) cnbr[e] = A.nbr[fr.ch_off + e];
         if (with_vnc)
         {
             // VertexNormalColor{pos, (0,0,0), (0.25,0.25,0.25)} (Src/Poly.cpp:690-694)
             float* vnc = (float*)(blob + L.vnc) + 9 * (size_t)fr.o_mv;
-            for (uint32_t i = tid; i < 9 * fr.mv_n; i += SURTR_WG)
+            for (uint32_t i = tid; i < 9 * fr.mv_n; i += group_size())
             {
                 const uint32_t v = i / 9, k = i % 9;
                 vnc[i] = k < 3 ? sp[3 * v + k] : (k < 6 ? 0.f : 0.25f);
             }
         }
         uint32_t* idx = (uint32_t*)(blob + L.idx) + fr.o_idx;
-        for (uint32_t e = tid; e < fr.idx_n; e += SURTR_WG) idx[e] = A.idx[fr.idx_off + e];
+        for (uint32_t e = tid; e < fr.idx_n; e += group_size()) idx[e] = A.idx[fr.idx_off + e];
     }
 }
 
@@ -1177,7 +1211,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
     __shared__ Shared sh;
     __shared__ LdsTopo L;
     Scratch S = carve(pool, 0);
-    for (uint32_t k = threadIdx.x; k < F; k += SURTR_WG) sh.planes[k] = planes[k];
+    for (uint32_t k = threadIdx.x; k < F; k += group_size()) sh.planes[k] = planes[k];
     __syncthreads();
     uint32_t n = 0, nh = 0;
     int err = clip_any(in, F, S, sh, L, [&](auto& T) -> int {
@@ -1196,11 +1230,11 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
 struct surtr_ctx
 {
     int device = 0;
-    uint32_t max_wg = 512, max_wg_faces = 1024;
+    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048;
     hipStream_t stream = nullptr;
     std::string err;
     // pieces
-    uint32_t n_pieces = 0, vmax = 0, hmax = 0;
+    uint32_t n_pieces = 0, vmax = 0, hmax = 0, cvmax = 0, chmax = 0;
     float *d_mpos = nullptr, *d_cpos = nullptr;
     uint32_t *d_mloff = nullptr, *d_mllen = nullptr, *d_mvo = nullptr, *d_cloff = nullptr, *d_cllen = nullptr, *d_cvo = nullptr;
     int32_t *d_mnbr = nullptr, *d_cnbr = nullptr;
@@ -1216,6 +1250,7 @@ struct surtr_ctx
     uint32_t user_cv = 0, user_ch = 0;
     uint64_t user_av = 0, user_ah = 0, user_ai = 0;
     ScratchPool pool{}; uint32_t n_wg = 0;
+    ScratchPool pool_small{}; uint32_t n_wg_small = 0;      // one-wave kernels (Convex clip, refit)
     FaceScratch fs{}; uint2* d_blk = nullptr; uint32_t blk_per_wg = 0;
     Arena arena{};
     PairRec* d_pairs = nullptr; uint32_t cap_pairs = 0;
@@ -1231,7 +1266,7 @@ struct surtr_ctx
     // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
     bool profiling = false;
 #ifndef SURTR_EMUL
-    hipEvent_t ev[16] = {};
+    hipEvent_t ev[16] = {};     // begin/end per kernel slot 0..7
 #endif
     bool ev_valid[8] = {};
 };
@@ -1287,6 +1322,7 @@ int surtr_create(int device, surtr_ctx** out)
             if (const char* e = getenv("SURTR_WG_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = (uint32_t)v; }
             ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
             ctx->max_wg_faces = (uint32_t)prop.multiProcessorCount * 4u;
+            ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * 8u;
         }
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
@@ -1304,7 +1340,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_cloff); free_dev(ctx->d_cllen); free_dev(ctx->d_cvo); free_dev(ctx->d_mnbr); free_dev(ctx->d_cnbr);
     free_dev(ctx->d_mtri); free_dev(ctx->d_ctri); free_dev(ctx->d_mrad); free_dev(ctx->d_crad);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
-    free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
     free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
@@ -1469,10 +1505,13 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const f
     int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri, &ctx->d_mrad,
                         vmax, hmax, tv, th);
     if (rc) return rc;
+    uint32_t cvmax = 0, chmax = 0;
     rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri, &ctx->d_crad,
-                    vmax, hmax, cv, chh);
+                    cvmax, chmax, cv, chh);
     if (rc) return rc;
-    ctx->n_pieces = n; ctx->vmax = vmax; ctx->hmax = hmax; ctx->tot_mv = tv; ctx->tot_mh = th;
+    ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
+    ctx->tot_mv = tv; ctx->tot_mh = th;
+    free_dev(ctx->pool_small.base); ctx->pool_small.base = nullptr;
     free_dev(ctx->pool.base); ctx->pool.base = nullptr;      // re-size scratch lazily
     free_dev(ctx->d_outside); ctx->d_outside = nullptr;
     HIPCHK(hipMalloc((void**)&ctx->d_outside, std::max<uint32_t>(n, 16)));
@@ -1555,6 +1594,20 @@ static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint
     return SURTR_OK;
 }
 
+static int ensure_scratch_small(surtr_ctx* ctx, uint32_t n_wg)
+{
+    // Convex solids: the input hull plus at most a few vertices per clipping plane
+    const uint32_t need_v = 2 * ctx->cvmax + 4 * SURTR_MAXF + 256, need_h = 2 * ctx->chmax + 12 * SURTR_MAXF + 1024;
+    const uint32_t CV = 2 * need_v + 1024, CH = 3 * need_h + 4096, VMAX = need_v;
+    if (ctx->pool_small.base && ctx->pool_small.CV >= CV && ctx->pool_small.CH >= CH && ctx->n_wg_small >= n_wg) return SURTR_OK;
+    free_dev(ctx->pool_small.base); ctx->pool_small.base = nullptr;
+    ctx->pool_small.CV = CV; ctx->pool_small.CH = CH; ctx->pool_small.VMAX = VMAX;
+    ctx->pool_small.per_wg = scratch_bytes_per_wg(CV, CH, VMAX);
+    ctx->n_wg_small = n_wg;
+    HIPCHK(hipMalloc((void**)&ctx->pool_small.base, ctx->pool_small.per_wg * n_wg));
+    return SURTR_OK;
+}
+
 static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
 {
     // Result sizes are data dependent; the default reserves the whole input once per 8 pairs plus slack.
@@ -1602,6 +1655,9 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
     int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(n_wg, ctx->n_wg));
     if (rc) return rc;
+    const uint32_t n_wg_small = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_small));
+    rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
+    if (rc) return rc;
     rc = ensure_arena(ctx, std::max(n_pairs, 1u));
     if (rc) return rc;
     hipStream_t st = ctx->stream;
@@ -1616,10 +1672,15 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad,
              ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->n_pieces};
     for (int i = 0; i < 8; ++i) ctx->ev_valid[i] = false;
+    PROF_BEGIN(6);
+    if (n_pairs)
+        hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list);
+    PROF_END(6);
     PROF_BEGIN(0);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool, ctx->arena, ctx->d_pairs, d_pair_list);
+                           ctx->pool, ctx->arena, ctx->d_pairs, d_pair_list);
     PROF_END(0);
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
@@ -1628,7 +1689,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (flags & SURTR_EVT_REFIT)
     {
         PROF_BEGIN(2);
-        hipLaunchKernelGGL(k_refit, dim3(n_wg), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool, ctx->arena);
+        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
         PROF_END(2);
     }
     if (flags & SURTR_EVT_RENDER)

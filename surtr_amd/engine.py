@@ -133,7 +133,7 @@ class Engine:
     def kernel_times(self):
         ms = (ctypes.c_float * 8)()
         self._ck(lib().surtr_kernel_times(self._h, ms))
-        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack")
+        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
     def upload_pieces(self, meshes, convexes):
