@@ -2,10 +2,14 @@
 """bench.py -- fragments/sec + ms/fracture-event on BASELINE.json's configs[3]:
 100k-triangle synthetic mesh (bumpy torus, 50 000 v / 100 000 tri) x 4096 Voronoi cells.
 
-A "step" is one fracture event on device-resident inputs: cell placement (A3), clip of Convex and
+A "step" is one fracture event per GPU on device-resident inputs: cell placement (A3), clip of Convex and
 Mesh against every cell + island split (A7, A8, A11), refit (A12), face extraction + ear clipping
 (A9, A10), pack of the fragment blob, and -- for N > 1 -- one all-gather of the blobs over RCCL.
-Cells are sharded in contiguous blocks over the ranks (strong scaling: total work fixed).
+
+Scaling: the path partitions into independent (cell, piece) units, so by default every rank gets a FIXED
+share -- one 4096-cell pattern of its own (seed 46354 + rank; rank 0 is exactly BASELINE configs[3]) -- and
+the job grows with N ("weak").  `--scaling strong` shards the ONE 4096-cell event of configs[3] in contiguous
+cell blocks instead; at N > 1 the default run also times that mode and reports it as `strong_sharded`.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -50,6 +54,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     args = ap.parse_args()
 
     import numpy as np
@@ -75,51 +80,60 @@ def main():
             dist.barrier()
     from surtr_amd import engine, scenes, multigpu
 
-    sc = scenes.torus_scene(args.cells)
-    eng = engine.Engine(local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    # the piece's Convex is the reference's ACH (PrepareFracture steps 1-6), built once at set-up
-    sc["convex"], _ = scenes.ach_convex(eng, sc["mesh"]["pos"])
-    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
-    eng.upload_pattern(sc["face_off"], sc["v012"])
-    cb, ce = engine.cell_block(rank, world, sc["n_cells"])
     flags = engine.EVT_REFIT | engine.EVT_RENDER
+    base = scenes.torus_scene(args.cells)          # seed 46354: BASELINE configs[3]
 
-    # sizing pass: blob capacity for the timed loop (sizes are identical every step: same inputs)
-    eng.place_cells(sc["scale"], sc["translate"])
-    counts = eng.fracture_event(cb, ce, flags=flags)
-    my_bytes = engine.blob_bytes(counts)
-    cap_t = torch.tensor([my_bytes], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
-    cap = (int(cap_t.item()) + 4095) // 4096 * 4096
-    blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
-    gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if world > 1 else blob
-
-    def step():
+    def setup(mode):
+        """Engine + inputs of this rank for one scaling mode; returns the step closure and what it gathers into."""
+        if mode == "weak" and rank > 0:
+            sc = scenes.make_scene(base["mesh"]["pos"], base["tris"], args.cells, seeds=scenes.uniform_seeds(args.cells, scenes.SEED + rank))
+        else:
+            sc = dict(base)
+        eng = engine.Engine(local_rank)
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        # the piece's Convex is the reference's ACH (PrepareFracture steps 1-6), built once at set-up
+        sc["convex"], _ = scenes.ach_convex(eng, sc["mesh"]["pos"])
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        eng.upload_pattern(sc["face_off"], sc["v012"])
+        cb, ce = (0, sc["n_cells"]) if mode == "weak" else engine.cell_block(rank, world, sc["n_cells"])
+        # sizing pass: blob capacity for the timed loop (sizes are identical every step: same inputs)
         eng.place_cells(sc["scale"], sc["translate"])
-        eng.fracture_event_async(cb, ce, flags=flags)
-        eng.pack_dev(blob.data_ptr(), cap)
+        counts = eng.fracture_event(cb, ce, flags=flags)
+        cap_t = torch.tensor([engine.blob_bytes(counts)], dtype=torch.int64, device=dev)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, blob)
+            dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        cap = (int(cap_t.item()) + 4095) // 4096 * 4096
+        blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if world > 1 else blob
+
+        def step():
+            eng.place_cells(sc["scale"], sc["translate"])
+            eng.fracture_event_async(cb, ce, flags=flags)
+            eng.pack_dev(blob.data_ptr(), cap)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, blob)
+        return sc, eng, step, blob, gathered, cap, (cb, ce)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
+    def timed(step, warmup, steps):
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        dt_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        return float(dt_t.item())
+
+    sc, eng, step, blob, gathered, cap, (cb, ce) = setup(args.scaling)
+    dt = timed(step, args.warmup, args.steps)
 
     # fragment totals over ranks (from the gathered blob headers)
     host = gathered.cpu().numpy()
@@ -145,6 +159,19 @@ def main():
             all_ms.setdefault(k, []).append(v)
     eng.set_profiling(False)
 
+    strong_extra = None
+    if world > 1 and args.scaling == "weak":
+        # the same run also times BASELINE configs[3] as ONE event sharded over the ranks (strong scaling)
+        eng.close()
+        sc2, eng2, step2, blob2, gathered2, cap2, _ = setup("strong")
+        k2 = max(3, min(args.steps, 10))
+        dt2 = timed(step2, 2, k2)
+        host2 = gathered2.cpu().numpy()
+        nf2 = sum(engine.unpack_blob(host2[r * cap2:(r + 1) * cap2])[0].n_frag for r in range(world))
+        strong_extra = {"ms_per_event": dt2 / k2 * 1e3, "fragments": nf2, "fragments_per_s": nf2 / (dt2 / k2), "steps": k2}
+        eng2.close()
+        eng = engine.Engine(local_rank)       # (closed below)
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_frag / (dt / args.steps)
@@ -163,11 +190,13 @@ def main():
                 traffic = None
         out = {
             "metric": "fragments/sec", "value": value, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "bumpy torus 50000 v / 100000 tri x %d Voronoi cells (BASELINE configs[3]), "
                                    "1 piece (mesh + its ACH convex), refit + triangulation on" % sc["n_cells"],
-                       "cells": sc["n_cells"], "fragments": total_frag, "parallelism": "cells sharded x%d" % world},
+                       "cells": sc["n_cells"] * (world if args.scaling == "weak" else 1), "fragments": total_frag,
+                       "parallelism": ("%d ranks x one %d-cell event each, one all-gather" % (world, sc["n_cells"])) if args.scaling == "weak"
+                                      else "one event, cells sharded x%d, one all-gather" % world},
             "ms_per_fracture_event": ms_per_step,
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
             "roofline": {"kernel": "k_clip_pairs", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -175,6 +204,8 @@ def main():
                          "algorithmic_bytes_per_launch": ab["clip_kernel"], "event_algorithmic_bytes": ab["event"],
                          "avg_launch_ms": clip_avg_ms},
         }
+        if strong_extra is not None:
+            out["strong_sharded"] = strong_extra
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             threads = 16          # the reference's pool: dp::thread_pool g_threadPool(16), Src/Surtr.cpp:28
