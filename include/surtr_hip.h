@@ -184,6 +184,27 @@ int surtr_hull_normals(uint32_t n, const float* points, uint32_t limit, uint32_t
 int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const float* normals, double max_axis_scale,
                           float plane_gap_inv, float* planes);
 
+/* ---- the step after the event: compound regrouping (host side) ---------------- */
+/* Surtr::ConvexOutOfSphere (Src/Surtr.cpp:2415-2458) for one Convex; sphere_points are already placed. */
+int surtr_convex_out_of_sphere(uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, uint32_t n_sphere,
+                               const float* sphere_points, const float origin[3], float radius, int* out);
+
+/* Bind sets of ApplyFracture (Src/Surtr.cpp:2103-2146) + MergeOutOfImpact (:2368-2403, when `partial`) +
+ * HandleConvexIsland (:2203-2366) on the un-refitted Convex solids of an event.
+ * Pieces [0, n_outside) are the pieces kept whole outside the impact sphere (bind 0); pieces
+ * [n_outside, n_pieces) are the event's fragments in output order, piece_cell[p] = their cell (consecutive
+ * fragments of one cell form one compound).  conv_nbr_off is global over all vertices, conv_nbr local per piece.
+ * Output: compound c owns compound_piece[compound_off[c] .. compound_off[c+1]) (ascending piece indices);
+ * compound 0 is the outside set; compound_off needs n_pieces + 2 entries, compound_piece n_pieces. */
+int surtr_regroup(uint32_t n_pieces, uint32_t n_outside, const int32_t* piece_cell,
+                  const uint32_t* conv_vert_off, const float* conv_pos, const uint32_t* conv_nbr_off, const int32_t* conv_nbr,
+                  int partial, uint32_t n_sphere, const float* sphere_points, const float origin[3], float radius,
+                  uint32_t* n_compounds, uint32_t* compound_off, int32_t* compound_piece);
+
+/* Runs m_refittingTask (and the output scan) on the fragments of the last event: the reference regroups on the
+ * un-refitted Convex solids and refits afterwards (Src/Surtr.cpp:1921-1939). */
+int surtr_event_refit(surtr_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

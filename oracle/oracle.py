@@ -32,7 +32,7 @@ def lib():
         L.orc_bag_free.argtypes = [ctypes.c_void_p]
         for name in ("orc_clip", "orc_extract_faces", "orc_render", "orc_moments", "orc_islands", "orc_unit_box",
                      "orc_neighbours_from_mesh", "orc_hull_normals", "orc_kdop_planes", "orc_refit",
-                     "orc_voronoi_cells", "orc_place_cells", "orc_seeds", "orc_event"):
+                     "orc_voronoi_cells", "orc_place_cells", "orc_seeds", "orc_event", "orc_regroup", "orc_convex_out_of_sphere"):
             getattr(L, name).restype = ctypes.c_void_p
         _LIB = L
     return _LIB
@@ -206,3 +206,24 @@ def event(meshes, convexes, plane_off, planes, outside=None, refit=True, render=
     out["vnc"] = out["vnc"].reshape(-1, 9)
     out["seconds"] = float(out["seconds"][0])
     return out
+
+
+def convex_out_of_sphere(solid, sphere_points, origin, radius):
+    pos, off, nbr = _solid_args(solid)
+    sp = np.ascontiguousarray(sphere_points, np.float32).reshape(-1, 3)
+    org = np.asarray(origin, np.float32)
+    bag = lib().orc_convex_out_of_sphere(ctypes.c_int(pos.shape[0]), _p(pos), _p(off), _p(nbr), ctypes.c_int(sp.shape[0]), _p(sp),
+                                         _p(org), ctypes.c_float(radius))
+    (f,) = _unbag(bag, [np.int32])
+    return bool(f[0])
+
+
+def regroup(convexes, piece_cell, n_outside=0, partial=False, sphere_points=None, origin=(0, 0, 0), radius=1.0):
+    cvo, cpos, coff, cnbr = _pack_pieces(convexes)
+    pc = np.ascontiguousarray(piece_cell, np.int32)
+    sp = np.zeros((0, 3), np.float32) if sphere_points is None else np.ascontiguousarray(sphere_points, np.float32).reshape(-1, 3)
+    org = np.asarray(origin, np.float32)
+    bag = lib().orc_regroup(ctypes.c_int(len(convexes)), ctypes.c_int(n_outside), _p(pc), _p(cvo), _p(cpos), _p(coff), _p(cnbr),
+                            ctypes.c_int(int(partial)), ctypes.c_int(sp.shape[0]), _p(sp), _p(org), ctypes.c_float(radius))
+    co, cp = _unbag(bag, [np.uint32, np.int32])
+    return co, cp

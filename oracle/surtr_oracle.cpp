@@ -965,6 +965,131 @@ static void fracture_cell(int cell, const std::vector<Plane>& planes, const std:
     }
 }
 
+
+// ------------------------------------------------- compound regrouping -----
+// Surtr::ConvexOutOfSphere, Src/Surtr.cpp:2415-2458.
+static bool convex_out_of_sphere(const Solid& S, const Faces& ext, const std::vector<V3>& cloud, V3 origin, float radius)
+{
+    bool none_inside = true;
+    for (size_t v = 0; v < S.size(); ++v)
+        if (length(sub(origin, S.pos[v])) < radius) { none_inside = false; break; }
+    if (!none_inside) return false;
+    for (const V3& po : cloud)
+    {
+        bool contain = true;
+        for (const auto& f : ext)
+        {
+            V3 n = normalize(cross(sub(S.pos[f[1]], S.pos[f[0]]), sub(S.pos[f[2]], S.pos[f[0]])));
+            float d = -dot(S.pos[f[0]], n);
+            float dist = dot(n, po) + d;
+            if (dist > 0) { contain = false; break; }
+        }
+        if (contain) return false;
+    }
+    return true;
+}
+
+// Surtr::MergeOutOfImpact, Src/Surtr.cpp:2368-2403.
+static void merge_out_of_impact(std::vector<std::set<int>>& bind, const std::vector<Solid>& conv, const std::vector<Faces>& ext,
+                                const std::vector<V3>& cloud, V3 origin, float radius)
+{
+    for (size_t i = 1; i < bind.size(); ++i)
+    {
+        std::set<int> outside;
+        for (int c : bind[i])
+            if (convex_out_of_sphere(conv[c], ext[c], cloud, origin, radius)) outside.insert(c);
+        if (!outside.empty())
+        {
+            std::set<int> rest;
+            std::set_difference(bind[i].begin(), bind[i].end(), outside.begin(), outside.end(), std::inserter(rest, rest.end()));
+            bind[i].swap(rest);
+            bind[0].insert(outside.begin(), outside.end());
+        }
+    }
+    bind.erase(std::remove_if(std::next(bind.begin()), bind.end(), [](const std::set<int>& s) { return s.empty(); }), bind.end());
+}
+
+// Surtr::HandleConvexIsland, Src/Surtr.cpp:2203-2366.
+static void handle_convex_island(std::vector<std::set<int>>& bind, const std::vector<Solid>& conv, const std::vector<Faces>& ext)
+{
+    struct Node { int cid; double absd; Plane plane; std::vector<V3> pts; };
+    std::vector<std::set<int>> fresh;
+    for (auto& local : bind)
+    {
+        if (local.size() <= 1) continue;
+        std::vector<Node> nodes;
+        for (int cid : local)
+            for (const auto& poly : ext[cid])
+            {
+                Node nd; nd.cid = cid;
+                for (int v : poly) nd.pts.push_back(conv[cid].pos[v]);
+                nd.plane = plane_from_points(nd.pts[0], nd.pts[1], nd.pts[2]);
+                nd.absd = std::abs(nd.plane.w);
+                nodes.push_back(nd);
+            }
+        std::sort(nodes.begin(), nodes.end(), [](const Node& a, const Node& b) { return a.absd < b.absd; });
+        std::map<int, std::set<int>> nei;
+        for (int cid : local) nei[cid] = std::set<int>();
+        for (int i = 0; i < (int)nodes.size() - 1; ++i)
+        {
+            bool lower = false;
+            for (int j = i + 1; j < (int)nodes.size(); ++j)
+            {
+                if (lower && nodes[i].absd > nodes[j].absd) break;
+                if (std::abs(nodes[i].absd - nodes[j].absd) > 1e-3) continue;
+                lower = true;
+                V3 in = normalize(pnormal(nodes[i].plane)), jn = normalize(pnormal(nodes[j].plane));
+                bool opposite = std::abs(1 + dot(in, jn)) < 1e-4;
+                if (!opposite) continue;
+                bool hit = false;
+                const int nj = (int)nodes[j].pts.size();
+                for (const V3& ip : nodes[i].pts)
+                {
+                    bool inc = true;
+                    for (int v = 0; v < nj; ++v)
+                        if (!on_right(nodes[j].pts[v], nodes[j].pts[(v + 1) % nj], ip, jn)) { inc = false; break; }
+                    if (inc) { hit = true; break; }
+                }
+                if (!hit)
+                {
+                    const int ni = (int)nodes[i].pts.size();
+                    for (const V3& jp : nodes[j].pts)
+                    {
+                        bool inc = true;
+                        for (int v = 0; v < ni; ++v)
+                            if (!on_right(nodes[i].pts[v], nodes[i].pts[(v + 1) % ni], jp, in)) { inc = false; break; }
+                        if (inc) { hit = true; break; }
+                    }
+                }
+                if (hit) { nei[nodes[i].cid].insert(nodes[j].cid); nei[nodes[j].cid].insert(nodes[i].cid); }
+            }
+        }
+        std::set<int> remain(local.begin(), local.end());
+        std::vector<std::set<int>> groups;
+        while (!remain.empty())
+        {
+            std::set<int> g;
+            std::list<int> q(1, *remain.begin());
+            while (!q.empty())
+            {
+                int cur = q.front(); q.pop_front();
+                if (remain.count(cur))
+                {
+                    g.insert(cur); remain.erase(cur);
+                    for (int a : nei[cur]) q.push_back(a);
+                }
+            }
+            groups.push_back(g);
+        }
+        if (groups.size() >= 2)
+        {
+            local = groups[0];
+            fresh.insert(fresh.end(), std::next(groups.begin()), groups.end());
+        }
+    }
+    bind.insert(bind.end(), fresh.begin(), fresh.end());
+}
+
 } // namespace orc
 
 // ============================================================ C interface ===
@@ -1297,6 +1422,54 @@ orc_bag* orc_event(int npieces,
     bag_put(b, cvoff); bag_put(b, cp); bag_put(b, cnoff); bag_put(b, cn);
     bag_put(b, vnc); bag_put(b, ioff); bag_put(b, idx); bag_put(b, secs);
     return b;
+}
+
+
+// -> [flag]
+orc_bag* orc_convex_out_of_sphere(int nv, const float* pos, const uint32_t* off, const int32_t* nbr, int ns, const float* sphere,
+                                  const float* origin, float radius)
+{
+    orc::Solid S = solid_in(nv, pos, off, nbr);
+    std::vector<orc::V3> cloud(ns);
+    for (int i = 0; i < ns; ++i) cloud[i] = orc::mk(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2]);
+    bool r = orc::convex_out_of_sphere(S, orc::extract_faces(S), cloud, orc::mk(origin[0], origin[1], origin[2]), radius);
+    std::vector<int32_t> f(1, r ? 1 : 0);
+    orc_bag* b = new orc_bag; bag_put(b, f); return b;
+}
+
+// Bind sets of ApplyFracture + MergeOutOfImpact (when partial) + HandleConvexIsland.
+// -> compound_off, compound_piece
+orc_bag* orc_regroup(int npieces, int noutside, const int32_t* piece_cell, const uint32_t* cvo, const float* cpos,
+                     const uint32_t* coff, const int32_t* cnbr, int partial, int ns, const float* sphere, const float* origin, float radius)
+{
+    std::vector<orc::Solid> conv(npieces);
+    std::vector<orc::Faces> ext(npieces);
+    for (int p = 0; p < npieces; ++p)
+    {
+        for (uint32_t v = cvo[p]; v < cvo[p + 1]; ++v)
+        {
+            conv[p].push(orc::mk(cpos[3 * v], cpos[3 * v + 1], cpos[3 * v + 2]), 1);
+            conv[p].nb.back().assign(cnbr + coff[v], cnbr + coff[v + 1]);
+        }
+        ext[p] = orc::extract_faces(conv[p]);
+    }
+    std::vector<std::set<int>> bind(1);
+    for (int p = 0; p < noutside; ++p) bind[0].insert(p);
+    for (int p = noutside; p < npieces; ++p)
+    {
+        if (p == noutside || piece_cell[p] != piece_cell[p - 1]) bind.emplace_back();
+        bind.back().insert(p);
+    }
+    if (partial)
+    {
+        std::vector<orc::V3> cloud(ns);
+        for (int i = 0; i < ns; ++i) cloud[i] = orc::mk(sphere[3 * i], sphere[3 * i + 1], sphere[3 * i + 2]);
+        orc::merge_out_of_impact(bind, conv, ext, cloud, orc::mk(origin[0], origin[1], origin[2]), radius);
+    }
+    orc::handle_convex_island(bind, conv, ext);
+    std::vector<uint32_t> co(1, 0); std::vector<int32_t> cp;
+    for (auto& s : bind) { for (int c : s) cp.push_back(c); co.push_back((uint32_t)cp.size()); }
+    orc_bag* b = new orc_bag; bag_put(b, co); bag_put(b, cp); return b;
 }
 
 } // extern "C"

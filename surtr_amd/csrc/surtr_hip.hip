@@ -1768,6 +1768,23 @@ int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* 
     return SURTR_OK;
 }
 
+int surtr_event_refit(surtr_ctx* ctx)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    if (!ctx->have_event) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    hipStream_t st = ctx->stream;
+    // k_refit pulls fragments from work queue 6
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors + 6, 0, 4, st));
+    PROF_BEGIN(2);
+    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
+    PROF_END(2);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    HIPCHK(hipGetLastError());
+    ctx->last_flags |= SURTR_EVT_REFIT;
+    return SURTR_OK;
+}
+
 int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts)
 {
     if (!ctx || !counts) return SURTR_E_INVALID;

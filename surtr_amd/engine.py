@@ -185,6 +185,9 @@ class Engine:
         self._ck(lib().surtr_fracture_pairs_async(self._h, ctypes.c_uint32(pc.shape[0]), _p(pc), _p(pp), ctypes.c_uint32(flags)))
         return self.event_counts()
 
+    def event_refit(self):
+        self._ck(lib().surtr_event_refit(self._h))
+
     def event_counts(self):
         c = Counts()
         self._ck(lib().surtr_event_counts(self._h, ctypes.byref(c)))
@@ -358,3 +361,35 @@ def kdop_ach_planes(points, normals, max_axis_scale, plane_gap_inv=2000.0):
     if rc:
         raise SurtrError(rc)
     return out
+
+
+def convex_out_of_sphere(solid, sphere_points, origin, radius):
+    pos = np.ascontiguousarray(solid["pos"], np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(solid["off"], np.uint32)
+    nbr = np.ascontiguousarray(solid["nbr"], np.int32)
+    sp = np.ascontiguousarray(sphere_points, np.float32).reshape(-1, 3)
+    org = np.ascontiguousarray(origin, np.float32)
+    out = ctypes.c_int()
+    rc = lib().surtr_convex_out_of_sphere(ctypes.c_uint32(pos.shape[0]), _p(pos), _p(off), _p(nbr), ctypes.c_uint32(sp.shape[0]), _p(sp),
+                                          _p(org), ctypes.c_float(radius), ctypes.byref(out))
+    if rc:
+        raise SurtrError(rc)
+    return bool(out.value)
+
+
+def regroup(convexes, piece_cell, n_outside=0, partial=False, sphere_points=None, origin=(0, 0, 0), radius=1.0):
+    """Bind sets + MergeOutOfImpact + HandleConvexIsland on un-refitted Convex solids -> (compound_off, compound_piece)."""
+    cvo, cpos, coff, cnbr = pack_solids(convexes)
+    pc = np.ascontiguousarray(piece_cell, np.int32)
+    sp = np.zeros((0, 3), np.float32) if sphere_points is None else np.ascontiguousarray(sphere_points, np.float32).reshape(-1, 3)
+    org = np.ascontiguousarray(origin, np.float32)
+    n = len(convexes)
+    co = np.zeros(n + 2, np.uint32)
+    cp = np.zeros(max(n, 1), np.int32)
+    nc = ctypes.c_uint32()
+    rc = lib().surtr_regroup(ctypes.c_uint32(n), ctypes.c_uint32(n_outside), _p(pc), _p(cvo), _p(cpos), _p(coff), _p(cnbr),
+                             ctypes.c_int(int(partial)), ctypes.c_uint32(sp.shape[0]), _p(sp), _p(org), ctypes.c_float(radius),
+                             ctypes.byref(nc), _p(co), _p(cp))
+    if rc:
+        raise SurtrError(rc)
+    return co[:nc.value + 1].copy(), cp[:co[nc.value]].copy()

@@ -1,0 +1,83 @@
+"""Row f1 (the step right after the event): bind sets, MergeOutOfImpact, HandleConvexIsland, and the
+regroup-then-refit order of Surtr::DoFracture (Src/Surtr.cpp:1921-1939).  Product host code vs the oracle."""
+import numpy as np
+import pytest
+
+from helpers import assert_event_equal
+from surtr_amd import meshgen, scenes
+
+
+def _two_level(engine_mod, n_first, n_second):
+    """First event on a blob -> its fragments become the pieces of one compound hit by a second pattern."""
+    sc = scenes.blob_scene(n_first)
+    eng = engine_mod.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    eng.fracture_event(0, n_first, flags=1)
+    first = eng.download()
+    meshes, convexes = scenes.fragments_as_pieces(first)
+    keep = [i for i, m in enumerate(meshes) if np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4]
+    meshes, convexes = [meshes[i] for i in keep], [convexes[i] for i in keep]
+    cells = engine_mod.voronoi_cells(scenes.uniform_seeds(n_second, scenes.SEED + 7))
+    fo, v012 = engine_mod.pattern_from_cells(cells)
+    eng.upload_pieces(meshes, convexes)
+    eng.upload_pattern(fo, v012)
+    eng.place_cells(sc["scale"], sc["translate"])
+    return sc, eng, meshes, convexes, fo, v012
+
+
+def _solids(ev, pre):
+    out = []
+    vo, no = ev[pre + "_vert_off"], ev[pre + "_nbr_off"]
+    for k in range(ev["frag_ids"].shape[0]):
+        a, b = int(vo[k]), int(vo[k + 1])
+        out.append({"pos": ev[pre + "_pos"][a:b], "off": (no[a:b + 1] - no[a]).astype(np.uint32), "nbr": ev[pre + "_nbr"][int(no[a]):int(no[b])]})
+    return out
+
+
+def test_regroup_and_refit_order(emul_engine, oracle):
+    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, 24, 5)
+    # event WITHOUT refit: the reference regroups on the un-refitted Convex solids
+    c = eng.fracture_event(0, 5, flags=2)
+    ev = eng.download()
+    conv = _solids(ev, "conv")
+    assert c.n_frag > 20
+    co, cp = emul_engine.regroup(conv, ev["frag_ids"][:, 0])
+    ro, rp = oracle.regroup(conv, ev["frag_ids"][:, 0])
+    assert np.array_equal(co, ro) and np.array_equal(cp, rp)
+    assert co.shape[0] - 1 >= 6           # bind 0 + one compound per cell (+ splits)
+    assert sorted(cp.tolist()) == list(range(c.n_frag))
+    # islands of compounds were actually found somewhere (pieces of one cell that do not touch)
+    sizes = np.diff(co.astype(np.int64))
+    assert sizes[0] == 0 and sizes.max() > 1
+    # ...then Refitting + SetExtract (:1938-1939): same result as an event with refit on
+    eng.event_refit()
+    after = eng.download()
+    planes = oracle.place_cells(v012, sc["scale"], sc["translate"])
+    ref = oracle.event(meshes, convexes, fo, planes, refit=True, render=True, threads=4)
+    assert_event_equal(after, ref)
+    eng.close()
+
+
+def test_partial_fracture_merges_out_of_impact(emul_engine, oracle):
+    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, 24, 5)
+    sphere, _ = meshgen.icosphere(2)
+    impact = (sc["translate"] + np.float32([0.2, 0.1, 0.0]) * sc["scale"]).astype(np.float32)
+    radius = float(0.2 * sc["scale"].max())
+    cloud = (sphere.astype(np.float32) * np.float32(0.5) * np.float32(radius) + impact).astype(np.float32)
+    # ApplyFracture(partial): pieces whose Convex is out of the sphere stay whole (:2107-2124)
+    outside = np.array([emul_engine.convex_out_of_sphere(cv, cloud, impact, radius) for cv in convexes], np.uint8)
+    assert all(bool(outside[i]) == oracle.convex_out_of_sphere(convexes[i], cloud, impact, radius) for i in range(len(convexes)))
+    assert 0 < outside.sum() < len(convexes)
+    c = eng.fracture_event(0, 5, outside=outside, flags=2)
+    ev = eng.download()
+    assert not np.isin(ev["frag_ids"][:, 1], np.nonzero(outside)[0]).any()
+    pieces = [convexes[i] for i in np.nonzero(outside)[0]] + _solids(ev, "conv")
+    n_out = int(outside.sum())
+    cell = np.concatenate([np.full(n_out, -1, np.int32), ev["frag_ids"][:, 0]])
+    co, cp = emul_engine.regroup(pieces, cell, n_outside=n_out, partial=True, sphere_points=cloud, origin=impact, radius=radius)
+    ro, rp = oracle.regroup(pieces, cell, n_outside=n_out, partial=True, sphere_points=cloud, origin=impact, radius=radius)
+    assert np.array_equal(co, ro) and np.array_equal(cp, rp)
+    assert np.diff(co.astype(np.int64))[0] >= n_out          # the outside compound only grows
+    eng.close()
