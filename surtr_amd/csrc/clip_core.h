@@ -141,6 +141,9 @@ struct SolidIn
     uint32_t nv;
     const uint8_t* tri;     // per vertex: 1 = every incident face is a triangle (nullptr = unknown)
     const float* rad;       // per vertex: radius of a ball around it holding every vertex of its incident faces (nullptr = unknown)
+    // spatially sorted copy for the pre-pass (nullptr = absent): sorted index i is vertex perm[i]; bsph[b] bounds
+    // the balls of the 64 vertices of sorted block b (centre xyz, radius w)
+    const uint32_t* perm; const float* pos_s; const float* rad_s; const float4* bsph;
 };
 
 __device__ __forceinline__ float plane_dist(const float4 pl, float x, float y, float z)
@@ -371,10 +374,12 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
         sh.hist[k] = 0; sh.zhist[k] = 0;
         if (k < F)
         {
-            // conservative: nl >= |n|; the second and third terms bound the float rounding of n.p + d for v and its neighbours
+            // conservative: distance to the plane of anything within r of p is >= (|n.p+d| - r|n|)/|n|; the second and
+            // third terms bound the float rounding of n.p + d for p and for the points of the ball
             const float4 pk = sh.planes[k];
-            const float nl = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);
-            sh.pmar[k] = make_float4(nl * 1.00101f, 1.0e-5f * fabsf(pk.w), 1.0e-5f * nl, 0.f);
+            const float n1 = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);                         // >= |n|, bounds the rounding terms
+            const float n2 = sqrtf(pk.x * pk.x + pk.y * pk.y + pk.z * pk.z) * 1.0001f;       // |n|, rounded up
+            sh.pmar[k] = make_float4(n2 * 1.00101f, 1.0e-5f * fabsf(pk.w), 1.0e-5f * n1, 0.f);
         }
     }
     if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; sh.misc[3] = 0; }
@@ -386,20 +391,69 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
-    for (uint32_t b0 = w; b0 < nbV; b0 += 4u * group_waves())
+    const bool sorted = in.bsph != nullptr && in.perm != nullptr && V < (1u << 24);
+    uint32_t nWork = nbV;                 // 64-blocks that need the per-vertex pass
+    uint32_t* und = T.aux2;               // (sorted path) the blocks the sphere test could not decide
+    if (sorted)
+    {
+        // ---- A0: one lane per block of 64 spatially close vertices: if the sphere around their balls is entirely on
+        // the cut side of plane k and entirely on the kept side of planes 0..k-1, all of them have fc = k and every one
+        // is dropped (same argument as the per-vertex ball test); nothing of the block is read.
+        for (uint32_t bq = tid; bq < nbV; bq += group_size()) bmask[bq] = 0ull;
+        if (tid == 0) sh.misc[4] = 0;
+        __syncthreads();
+        for (uint32_t sb = tid; sb < nbV; sb += group_size())
+        {
+            const float4 sp = in.bsph[sb];
+            const float mag = fabsf(sp.x) + fabsf(sp.y) + fabsf(sp.z) + sp.w;
+            uint32_t f = 0xFFu;
+            for (uint32_t k = 0; k < F; ++k)
+            {
+                const float4 mk = sh.pmar[k];
+                const float sk = plane_dist(sh.planes[k], sp.x, sp.y, sp.z);
+                const float margin = sp.w * mk.x + mk.y + mk.z * mag;
+                if (sk > margin) { f = k; break; }
+                if (!(sk < -margin)) break;
+            }
+            if (f != 0xFFu)
+            {
+                const uint32_t left = V - (sb << SURTR_LSH);
+                atomicAdd(&sh.hist[f], left < SURTR_LANES ? left : (uint32_t)SURTR_LANES);
+            }
+            else und[atomicAdd(&sh.misc[4], 1u)] = sb;
+        }
+        __syncthreads();
+        nWork = sh.misc[4];
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        if (tid == 0 && V > 10000u) { atomicAdd(&g_stamp[45], (unsigned long long)nWork); atomicAdd(&g_stamp[46], (unsigned long long)nbV); }
+#endif
+    }
+    for (uint32_t b0 = w; b0 < nWork; b0 += 4u * group_waves())
     {
         // four 64-blocks per wave iteration: their loads are in flight together, and every plane fetched
         // from LDS is applied to all four (planes outermost: one LDS fetch per plane, four independent chains)
         float px4[4], py4[4], pz4[4], rv4[4], mag4[4];
-        uint32_t f4[4]; bool done4[4], clear4[4], valid4[4];
+        uint32_t f4[4], id4[4]; bool done4[4], clear4[4], valid4[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
         {
-            const uint32_t v = ((b0 + g * group_waves()) << SURTR_LSH) + l;
-            valid4[g] = v < V;
-            const uint32_t vv = valid4[g] ? v : 0u;
-            px4[g] = in.pos[3 * vv]; py4[g] = in.pos[3 * vv + 1]; pz4[g] = in.pos[3 * vv + 2];
-            rv4[g] = (in.rad != nullptr && V < (1u << 24)) ? in.rad[vv] : -1.f;
+            const uint32_t wb = b0 + g * group_waves();
+            const uint32_t blk = (sorted && wb < nWork) ? und[wb] : wb;
+            const uint32_t i = (blk << SURTR_LSH) + l;
+            valid4[g] = wb < nWork && i < V;
+            const uint32_t ii = valid4[g] ? i : 0u;
+            if (sorted)
+            {
+                id4[g] = in.perm[ii];
+                px4[g] = in.pos_s[3 * ii]; py4[g] = in.pos_s[3 * ii + 1]; pz4[g] = in.pos_s[3 * ii + 2];
+                rv4[g] = in.rad_s[ii];
+            }
+            else
+            {
+                id4[g] = ii;
+                px4[g] = in.pos[3 * ii]; py4[g] = in.pos[3 * ii + 1]; pz4[g] = in.pos[3 * ii + 2];
+                rv4[g] = (in.rad != nullptr && V < (1u << 24)) ? in.rad[ii] : -1.f;
+            }
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -430,9 +484,9 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
 #pragma unroll
         for (int g = 0; g < 4; ++g)
         {
-            const uint32_t b = b0 + g * group_waves();
-            if (b >= nbV) break;
-            const uint32_t v = (b << SURTR_LSH) + l;
+            const uint32_t wb = b0 + g * group_waves();
+            if (wb >= nWork) break;
+            const uint32_t v = id4[g];
             const uint32_t f = f4[g];
             const bool keep = valid4[g] && f == 0xFFu;
             const bool drop = valid4[g] && !keep && clear4[g];     // cannot be in-plane anywhere before fc (|s| > margin there)
@@ -443,7 +497,18 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
 #else
             const unsigned long long mk = __ballot(keep), mn = __ballot(need);
 #endif
-            if (l == 0) bmask[b] = mk;
+            if (sorted)
+            {
+                if (keep)
+                {
+#ifdef SURTR_EMUL
+                    bmask[v >> SURTR_LSH] |= 1ull << (v & (SURTR_LANES - 1u));
+#else
+                    atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
+#endif
+                }
+            }
+            else if (l == 0) bmask[wb] = mk;
             if (mn)
             {
                 uint32_t base = 0;
@@ -457,6 +522,9 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     STAMP(0);
     // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
     const uint32_t nNeedy = sh.misc[3];
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+    if (tid == 0 && V > 10000u) atomicAdd(&g_stamp[47], (unsigned long long)nNeedy);
+#endif
     for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += group_size())
     {
         const uint32_t i = i0 + l;
@@ -791,6 +859,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         };
         uint32_t M = 0, nCut = 0;
         scan_blocks(nS, T.blk, sh, cutfn, M, nCut);
+        STAMP(8);
         if (nS + M > T.capV || T.hUsed + 3u * M + (anyZero ? T.hUsed : 0u) > T.capH || nS + M >= TT::SENT)
         {
             // out of slots: squeeze the tombstones out (order-preserving, like :464-495) and retry this plane once
@@ -829,6 +898,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 }
             }
             __syncthreads();
+            STAMP(9);
             // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
             uint32_t* keptof = T.aux1;     // kept end of every new vertex, for the back-link patch below
             bool dup = false;
@@ -857,6 +927,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             }
             if (dup) pf[3] = 1;
             __syncthreads();
+            STAMP(10);
             const bool ordered = pf[3] != 0;
             // links of the two ends (:350-354): "find the clipped vertex in the kept vertex's ring, overwrite it"
             if (!ordered)
@@ -917,6 +988,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             }
             if (bad) pf[4] = 1;
             __syncthreads();
+            STAMP(12);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
             if (tid == 0) { atomicAdd(&g_stamp[42], (unsigned long long)sh.misc[5]); atomicAdd(&g_stamp[43], 1ull); atomicAdd(&g_stamp[44], (unsigned long long)((M + group_size() - 1) / group_size())); sh.misc[5] = 0; }
 #endif
@@ -924,6 +996,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             for (uint32_t t = tid; t < M; t += group_size()) if (T.pcnt[t] != 1u) bad = true;
             if (bad) pf[4] = 1;
             __syncthreads();
+            STAMP(13);
             serial = pf[4] != 0;
             if (!serial)
             {

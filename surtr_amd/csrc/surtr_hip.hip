@@ -56,7 +56,9 @@ struct Arena
 struct Pieces
 {
     const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri; const float* mrad;
+    const uint32_t* mperm; const float* mpos_s; const float* mrad_s; const float4* mbsph; const uint32_t* mbo;
     const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri; const float* crad;
+    const uint32_t* cperm; const float* cpos_s; const float* crad_s; const float4* cbsph; const uint32_t* cbo;
     uint32_t n;
 };
 
@@ -398,7 +400,8 @@ __global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const flo
             for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
             __syncthreads();
             const uint32_t c0 = P.cvo[piece];
-            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0};
+            SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
+                        P.cperm + c0, P.cpos_s + 3 * (size_t)c0, P.crad_s + c0, P.cbsph + P.cbo[piece]};
             err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
                 if (T.nLive == 0) return 0;
                 return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
@@ -446,7 +449,8 @@ __global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pi
         for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
         __syncthreads();
         const uint32_t m0 = P.mvo[piece];
-        SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0};
+        SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
+                    P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
         int err = clip_any(min, F, S, sh, L, [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_mesh_islands(T, sh, A, rec);
@@ -657,7 +661,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
-        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr};
+        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
         int err = clip_any(cin, 8, S, sh, L, [&](auto& T) -> int {
@@ -1240,6 +1244,9 @@ struct surtr_ctx
     int32_t *d_mnbr = nullptr, *d_cnbr = nullptr;
     uint8_t *d_mtri = nullptr, *d_ctri = nullptr;
     float *d_mrad = nullptr, *d_crad = nullptr;
+    uint32_t *d_mperm = nullptr, *d_cperm = nullptr, *d_mbo = nullptr, *d_cbo = nullptr;
+    float *d_mpos_s = nullptr, *d_cpos_s = nullptr, *d_mrad_s = nullptr, *d_crad_s = nullptr;
+    float4 *d_mbsph = nullptr, *d_cbsph = nullptr;
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
     uint32_t n_cells = 0, n_faces = 0;
@@ -1339,6 +1346,8 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mpos); free_dev(ctx->d_cpos); free_dev(ctx->d_mloff); free_dev(ctx->d_mllen); free_dev(ctx->d_mvo);
     free_dev(ctx->d_cloff); free_dev(ctx->d_cllen); free_dev(ctx->d_cvo); free_dev(ctx->d_mnbr); free_dev(ctx->d_cnbr);
     free_dev(ctx->d_mtri); free_dev(ctx->d_ctri); free_dev(ctx->d_mrad); free_dev(ctx->d_crad);
+    free_dev(ctx->d_mperm); free_dev(ctx->d_cperm); free_dev(ctx->d_mbo); free_dev(ctx->d_cbo); free_dev(ctx->d_mpos_s); free_dev(ctx->d_cpos_s);
+    free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
@@ -1395,6 +1404,7 @@ static int check_solid(uint32_t nv, const uint32_t* off, const int32_t* nbr)
 
 static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const float* pos, const uint32_t* off, const int32_t* nbr,
                       float** d_pos, uint32_t** d_loff, uint32_t** d_llen, int32_t** d_nbr, uint32_t** d_vo, uint8_t** d_tri, float** d_rad,
+                      uint32_t** d_perm, float** d_pos_s, float** d_rad_s, float4** d_bsph, uint32_t** d_bo,
                       uint32_t& vmax, uint32_t& hmax, uint64_t& totv, uint64_t& toth)
 {
     const uint32_t V = vo[n];
@@ -1492,6 +1502,67 @@ static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const floa
     HIPCHK(hipMemcpy(*d_tri, tri.data(), (size_t)V, hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)d_rad, std::max<size_t>(16, (size_t)V * 4)));
     HIPCHK(hipMemcpy(*d_rad, rad.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+    // Spatially sorted copy for the pre-pass: Morton order per piece, 64-vertex blocks with a bounding sphere that
+    // also holds every vertex's ball (radius rad[v]).
+    {
+        std::vector<uint32_t> perm(V), bo(n + 1, 0);
+        std::vector<float> pos_s(3 * (size_t)V), rad_s(V);
+        std::vector<float> bs;
+        for (uint32_t p = 0; p < n; ++p)
+        {
+            const uint32_t a = vo[p], b = vo[p + 1], m = b - a;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t v = a; v < b; ++v) for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], (double)pos[3 * (size_t)v + c]); hi[c] = std::max(hi[c], (double)pos[3 * (size_t)v + c]); }
+            std::vector<std::pair<uint32_t, uint32_t>> key(m);
+            for (uint32_t v = 0; v < m; ++v)
+            {
+                uint32_t code = 0;
+                for (int c = 0; c < 3; ++c)
+                {
+                    const double ext = hi[c] - lo[c];
+                    uint32_t q = ext > 0 ? (uint32_t)std::min(1023.0, std::max(0.0, (pos[3 * (size_t)(a + v) + c] - lo[c]) / ext * 1024.0)) : 0u;
+                    for (int bit = 0; bit < 10; ++bit) code |= ((q >> bit) & 1u) << (3 * bit + c);
+                }
+                key[v] = {code, v};
+            }
+            std::sort(key.begin(), key.end());
+            for (uint32_t i = 0; i < m; ++i)
+            {
+                const uint32_t v = key[i].second;
+                perm[a + i] = v;
+                for (int c = 0; c < 3; ++c) pos_s[3 * (size_t)(a + i) + c] = pos[3 * (size_t)(a + v) + c];
+                rad_s[a + i] = rad[a + v];
+            }
+            const uint32_t nb = (m + SURTR_LANES - 1) / SURTR_LANES;
+            for (uint32_t blk = 0; blk < nb; ++blk)
+            {
+                const uint32_t i0 = blk * SURTR_LANES, i1 = std::min(m, i0 + (uint32_t)SURTR_LANES);
+                double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+                for (uint32_t i = i0; i < i1; ++i) for (int c = 0; c < 3; ++c) { blo[c] = std::min(blo[c], (double)pos_s[3 * (size_t)(a + i) + c]); bhi[c] = std::max(bhi[c], (double)pos_s[3 * (size_t)(a + i) + c]); }
+                const float cx = (float)((blo[0] + bhi[0]) / 2), cy = (float)((blo[1] + bhi[1]) / 2), cz = (float)((blo[2] + bhi[2]) / 2);
+                double R = 0;
+                for (uint32_t i = i0; i < i1; ++i)
+                {
+                    const double dx = pos_s[3 * (size_t)(a + i)] - (double)cx, dy = pos_s[3 * (size_t)(a + i) + 1] - (double)cy, dz = pos_s[3 * (size_t)(a + i) + 2] - (double)cz;
+                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)rad_s[a + i]);
+                }
+                bs.push_back(cx); bs.push_back(cy); bs.push_back(cz); bs.push_back((float)(R * 1.000001) + 1e-30f);
+            }
+            bo[p + 1] = bo[p] + nb;
+        }
+        free_dev(*d_perm); free_dev(*d_pos_s); free_dev(*d_rad_s); free_dev(*d_bsph); free_dev(*d_bo);
+        *d_perm = nullptr; *d_pos_s = nullptr; *d_rad_s = nullptr; *d_bsph = nullptr; *d_bo = nullptr;
+        HIPCHK(hipMalloc((void**)d_perm, std::max<size_t>(16, (size_t)V * 4)));
+        HIPCHK(hipMalloc((void**)d_pos_s, std::max<size_t>(16, (size_t)V * 12)));
+        HIPCHK(hipMalloc((void**)d_rad_s, std::max<size_t>(16, (size_t)V * 4)));
+        HIPCHK(hipMalloc((void**)d_bsph, std::max<size_t>(16, bs.size() * 4)));
+        HIPCHK(hipMalloc((void**)d_bo, (size_t)(n + 1) * 4));
+        HIPCHK(hipMemcpy(*d_perm, perm.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(*d_pos_s, pos_s.data(), (size_t)V * 12, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(*d_rad_s, rad_s.data(), (size_t)V * 4, hipMemcpyHostToDevice));
+        if (!bs.empty()) HIPCHK(hipMemcpy(*d_bsph, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(*d_bo, bo.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    }
     totv = V; toth = H;
     return SURTR_OK;
 }
@@ -1503,10 +1574,12 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const f
     (void)hipSetDevice(ctx->device);
     uint32_t vmax = 0, hmax = 0; uint64_t tv = 0, th = 0, cv = 0, chh = 0;
     int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri, &ctx->d_mrad,
+                        &ctx->d_mperm, &ctx->d_mpos_s, &ctx->d_mrad_s, &ctx->d_mbsph, &ctx->d_mbo,
                         vmax, hmax, tv, th);
     if (rc) return rc;
     uint32_t cvmax = 0, chmax = 0;
     rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri, &ctx->d_crad,
+                    &ctx->d_cperm, &ctx->d_cpos_s, &ctx->d_crad_s, &ctx->d_cbsph, &ctx->d_cbo,
                     cvmax, chmax, cv, chh);
     if (rc) return rc;
     ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
@@ -1669,8 +1742,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         HIPCHK(hipMemcpyAsync(ctx->d_outside, outside, ctx->n_pieces, hipMemcpyHostToDevice, st));
         d_out = ctx->d_outside;
     }
-    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad,
-             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->n_pieces};
+    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad, ctx->d_mperm, ctx->d_mpos_s, ctx->d_mrad_s, ctx->d_mbsph, ctx->d_mbo,
+             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->d_cperm, ctx->d_cpos_s, ctx->d_crad_s, ctx->d_cbsph, ctx->d_cbo, ctx->n_pieces};
     for (int i = 0; i < 8; ++i) ctx->ev_valid[i] = false;
     PROF_BEGIN(6);
     if (n_pairs)
@@ -1939,7 +2012,7 @@ int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const u
     CK(hipMemcpy(d_llen, llen.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
     if (n_planes) CK(hipMemcpy(d_pl, planes, (size_t)n_planes * 16, hipMemcpyHostToDevice));
-    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr, nullptr};
+    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_clip_single, dim3(1), dim3(SURTR_WG), 0, ctx->stream, in, d_pl, n_planes, ctx->pool, d_opos, d_ooff, d_onbr,
                        d_ollen, capv, caph, d_res);
     CK(hipGetLastError());
