@@ -1,0 +1,65 @@
+"""GPU-vs-oracle fuzz: random meshes, seeds, cell counts and piece sets; full-array comparison.
+Usage: python scripts/fuzz_gpu.py [n_cases] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+from oracle import oracle as O
+from surtr_amd import engine as E, scenes as S, meshgen as G
+from helpers import assert_event_equal
+
+def random_scene(rng):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        v, t = G.bumpy_torus(int(rng.integers(20, 180)), int(rng.integers(12, 120)), R=float(rng.uniform(0.6, 1.5)), r0=float(rng.uniform(0.15, 0.4)))
+    elif kind == 1:
+        v, t = G.blob(int(rng.integers(2, 5)), scale=float(rng.uniform(0.5, 80.0)))
+    elif kind == 2:
+        v, t = G.cube(float(rng.uniform(0.3, 5.0)))
+    else:
+        v, t = G.blob(3, scale=1.0)
+        v2, t2 = G.cube(0.4)
+        v = np.concatenate([v, v2 + np.float32([3, 0, 0])]); t = np.concatenate([t, t2 + len(v) - len(v2)])
+    v = (v + rng.uniform(-1, 1, 3).astype(np.float32) * np.float32(rng.uniform(0, 3))).astype(np.float32)
+    n_cells = int(rng.choice([3, 8, 17, 64, 150, 400]))
+    seeds = S.uniform_seeds(n_cells, int(rng.integers(1, 1 << 30)))
+    return S.make_scene(v, t, n_cells, seeds=seeds), kind
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
+    eng = E.Engine(0)
+    bad = 0
+    t0 = time.time()
+    for case in range(n):
+        sc, kind = random_scene(rng)
+        use_ach = bool(rng.integers(0, 2))
+        if use_ach:
+            sc["convex"], _ = S.ach_convex(eng, sc["mesh"]["pos"])
+        flags = int(rng.choice([0, 1, 2, 3, 3, 3]))
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        eng.upload_pattern(sc["face_off"], sc["v012"])
+        # the reference places patterns both over the AABB and around an impact point
+        scale = sc["scale"] * np.float32(rng.uniform(0.6, 2.2)); shift = sc["translate"] + (rng.uniform(-0.3, 0.3, 3) * sc["scale"]).astype(np.float32)
+        eng.place_cells(scale, shift)
+        c = eng.fracture_event(0, sc["n_cells"], flags=flags)
+        got = eng.download()
+        planes = O.place_cells(sc["v012"], scale, shift)
+        ref = O.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=bool(flags & 1), render=bool(flags & 2), threads=8)
+        try:
+            assert c.status == 0
+            assert_event_equal(got, ref, render=bool(flags & 2))
+            ok = True
+        except AssertionError as e:
+            ok = False; bad += 1
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez_compressed("gpurun_out/fuzz_fail_%d.npz" % case, mesh_pos=sc["mesh"]["pos"], mesh_off=sc["mesh"]["off"], mesh_nbr=sc["mesh"]["nbr"],
+                                conv_pos=sc["convex"]["pos"], conv_off=sc["convex"]["off"], conv_nbr=sc["convex"]["nbr"], face_off=sc["face_off"], planes=planes, flags=flags)
+            print("  FAIL case", case, str(e)[:200], flush=True)
+        print("case %d kind %d V %d cells %d ach %d flags %d frags %d verts %d idx %d %s  (%.0fs)" % (case, kind, sc["mesh"]["pos"].shape[0], sc["n_cells"], use_ach, flags, c.n_frag, c.mesh_verts, c.n_idx, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
+    print("FUZZ DONE: %d cases, %d mismatches" % (n, bad))
+    eng.close()
+    sys.exit(1 if bad else 0)
+
+if __name__ == "__main__":
+    main()

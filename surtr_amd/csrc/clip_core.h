@@ -125,7 +125,7 @@ struct Shared
     uint32_t hist[SURTR_MAXF + 1];    // after the pre-pass: dropped vertices still alive after plane k
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t wsum[2 * SURTR_NWAVE];
-    uint32_t flagCut, flagKeep, flagZero, flagBad, flagErr;
+    uint32_t flagBad, flagErr;
     uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;
     uint32_t misc[8];

@@ -2,8 +2,9 @@
 //
 // Event pipeline (all on the caller's HIP stream, inputs resident in HBM):
 //   k_place_cells   A3   Polygon3D::Scale/Translate + ConstructFacePlane      (Src/VMACH.cpp:302-310, 506-534)
-//   k_clip_pairs    A7+A8+A11  one workgroup per (cell, piece): clip Convex, clip Mesh, label islands,
-//                        park the result in the arena                          (Src/Surtr.cpp:1457-1504, Src/Poly.cpp:265-500)
+//   k_clip_convex   A7   Convex of every (cell, piece) pair, one wave per task (Src/Surtr.cpp:1466-1468)
+//   k_clip_pairs    A7+A8+A11  Mesh of every pair whose Convex survived: clip, label islands,
+//                        park the result in the arena                          (Src/Surtr.cpp:1470-1504, Src/Poly.cpp:265-500)
 //   k_frag_table    A11  cell-major fragment table                             (Src/Surtr.cpp:2133-2146)
 //   k_refit         A12  limit-4 hull normals + k-DOP slabs + clip Convex      (Src/Surtr.cpp:1449-1455)
 //   k_faces         A9+A10  ExtractFaces + EarClipping of every Mesh           (Src/Poly.cpp:89-126, 764-913)
@@ -560,9 +561,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
     __shared__ Shared sh;
     __shared__ ArgF slotF[SURTR_NWAVE];
     __shared__ ArgD slotD[SURTR_NWAVE];
-    __shared__ float hp[4][3];
     __shared__ float nrm[4][3];
-    __shared__ ArgF kmin[4][SURTR_NWAVE], kmax[4][SURTR_NWAVE];
     __shared__ LdsTopoSmall L;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
@@ -675,7 +674,6 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             frags[f] = fr;
         }
         if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
-        (void)kmin; (void)kmax; (void)hp;
     }
 }
 
