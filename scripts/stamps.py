@@ -15,14 +15,14 @@ L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
 names = ["pre: A1 stream", "pre: A2 exact", "pre: A3+emit", "pre: hist", "plane: classify", "plane: cut links patch", "plane: relink finalize/serial", "plane: tombstones",
-         "plane: cut scan", "plane: cut sparse sweep", "plane: cut dense create", "-", "plane: walks", "plane: pred check"]
-tot = sum(buf[i] for i in range(14))
+         "plane: cut scan", "plane: cut sparse sweep", "plane: cut dense create", "plane: chain jump", "plane: walks (first 12 steps)", "plane: pred check", "plane: resumed walks"]
+tot = sum(buf[i] for i in range(15))
 for i, n in enumerate(names):
     print("%-20s %14d  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
 print("total cycles (lane0, summed over WGs)", tot)
 print("serial planes", buf[19], "solids redone on global scratch", buf[20], "squeezes", buf[31])
 print("overflow causes: toolong %d, n>capV %d, hsum>capEmit %d, M>capAux %d, after squeeze %d, zw %d, ring len %d" % tuple(buf[32:39]))
-print("walks: %d walkers, %d steps (avg %.2f); per plane: %d planes, sum of max walk %d (avg max %.1f), walker rounds %d" % (buf[41], buf[40], buf[40]/max(buf[41],1), buf[43], buf[42], buf[42]/max(buf[43],1), buf[44]))
+print("regular (parallel-relink) planes: %d, with chain jumping: %d" % (buf[43], buf[40]))
 print("prepass (big solids): undecided blocks %d of %d (%.1f%%), needy vertices %d" % (buf[45], buf[46], 100.0*buf[45]/max(buf[46],1), buf[47]))
 print("pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[21 + i] for i in range(11)])
 print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[18], 1), buf[17], buf[18]))

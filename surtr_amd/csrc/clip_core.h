@@ -53,8 +53,8 @@
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
 __device__ unsigned long long g_stamp[48];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
-#define STAMP(i) do { if (threadIdx.x == 0) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); st_t0 = st_t1; } } while (0)
-#define COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&g_stamp[i], 1ull); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0 && blockDim.x > 64) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); st_t0 = st_t1; } } while (0)
+#define COUNT(i) do { if (threadIdx.x == 0 && blockDim.x > 64) atomicAdd(&g_stamp[i], 1ull); } while (0)
 #else
 #define COUNT(i) do { } while (0)
 #define STAMP_DECL
@@ -63,6 +63,7 @@ __device__ unsigned long long g_stamp[48];
 
 #define SURTR_MAXF 127          // planes per cell (Voronoi cells have ~15, an ACH k-DOP up to 72)
 #define SURTR_DEAD (-3)          // comp of a tombstone
+#define SURTR_WALK0 12u        // walk steps before the cap-run shortcut is built
 #define SURTR_OVERFLOW 100       // internal: the solid does not fit this Topo, redo with the larger one
 
 // LDS-resident topology: capacities per workgroup
@@ -357,15 +358,14 @@ __device__ void collapse_serial(Topo<TT>& T, uint32_t n1)
 }
 
 // ---------------------------------------------------------------------------
-// Pre-pass: builds the reduced solid of `in` for the planes sh.planes[0..F) in T.
-// bmask/bblk: one word / one (count, ring entries) pair per 64 input vertices (LDS or global).
-// capH_emit: ring entries available while the masks are still in use.
-// Returns 0 or SURTR_OVERFLOW (does not fit T) -- uniform over the workgroup.
-template <class TT>
-__device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh, unsigned long long* bmask, uint2* bblk,
-                       uint32_t capH_emit, unsigned long long* spill_mask, uint2* spill_blk)
+// The pre-pass has two halves, so that a kernel of its own can run the first one without a Topo:
+//   prepass_select  which vertices form the reduced solid (bit mask + per-block counts), hist/zhist; n vertices,
+//                   hsum ring entries; sh.flagBad = a kept vertex has more neighbours than a narrow ring may hold
+//   prepass_emit    writes the reduced solid into T (any memory)
+// needy/und: u32 work lists (V and V/64 entries).
+__device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared& sh, unsigned long long* bmask, uint2* bblk,
+                                      uint32_t* needy, uint32_t* und, uint32_t& n_out, uint32_t& hsum_out)
 {
-    typedef typename TT::idx_t I;
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
     STAMP_DECL;
@@ -385,15 +385,14 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; sh.misc[3] = 0; }
     __syncthreads();
     const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
-    uint32_t* needy = T.aux0;      // work list of vertices that need the exact neighbour test: v | fc << 24
-    uint32_t* orig = T.aux1;       // reduced index -> original vertex
+    // needy: work list of vertices that need the exact neighbour test: v | fc << 24
 
     // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
     const bool sorted = in.bsph != nullptr && in.perm != nullptr && V < (1u << 24);
     uint32_t nWork = nbV;                 // 64-blocks that need the per-vertex pass
-    uint32_t* und = T.aux2;               // (sorted path) the blocks the sphere test could not decide
+    // und: (sorted path) the blocks the sphere test could not decide
     if (sorted)
     {
         // ---- A0: one lane per block of 64 spatially close vertices: if the sphere around their balls is entirely on
@@ -604,7 +603,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
                 const uint32_t v = (b << SURTR_LSH) + l;
                 const bool keep = (m >> l) & 1ull;
                 const uint32_t deg = keep ? in.llen[v] : 0u;
-                if (deg > TT::MAXLEN / 2u) toolong = true;
+                if (deg > InLds::MAXLEN / 2u) toolong = true;
                 inc = wave_incl_scan2(make_uint2(keep ? 1u : 0u, deg));
             }
             if (l == SURTR_LANES - 1u) bblk[b] = inc;
@@ -614,21 +613,30 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     __syncthreads();
     uint32_t n = 0, hsum = 0;
     scan_block_array(nbV, bblk, sh, n, hsum);
-    const bool toolong = sh.flagBad != 0;
     __syncthreads();
-    if (spill_mask != nullptr && spill_mask != bmask)
+    n_out = n; hsum_out = hsum;
+}
+
+// hist[k] := dropped vertices still alive after plane k = sum_{f>k} hist[f] (once per pre-pass, after prepass_select)
+__device__ inline void prepass_finish_hist(const uint32_t F, Shared& sh)
+{
+    __syncthreads();
+    if (threadIdx.x == 0)
     {
-        // a global copy of the bit mask always exists (clip_planes' all-in-plane corner case reads it).  The LDS
-        // masks share the tail of the ring area; a band that needs all of it moves both mask arrays to global scratch.
-        const bool spill = hsum > capH_emit && hsum <= T.capH;
-        for (uint32_t b = tid; b < nbV; b += group_size()) { spill_mask[b] = bmask[b]; if (spill) spill_blk[b] = bblk[b]; }
-        __syncthreads();
-        if (spill) { bmask = spill_mask; bblk = spill_blk; capH_emit = T.capH; }
+        uint32_t run = 0;
+        for (int k = (int)F - 1; k >= 0; --k) { const uint32_t h = sh.hist[k]; sh.hist[k] = run; run += h; }
     }
-    if (toolong) COUNT(32);
-    if (n > T.capV) COUNT(33);
-    if (hsum > capH_emit) COUNT(34);
-    if (toolong || n > T.capV || hsum > capH_emit || n >= TT::SENT) return SURTR_OVERFLOW;
+    __syncthreads();
+}
+
+template <class TT>
+__device__ void prepass_emit(const SolidIn in, Topo<TT>& T, const unsigned long long* bmask, const uint2* bblk, uint32_t* orig,
+                             const uint32_t n, const uint32_t hsum)
+{
+    typedef typename TT::idx_t I;
+    const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id();
+    const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
+    STAMP_DECL;
     // ---- emit: slot table first (sparse sweep, no gathers), then rings densely over the kept vertices ----
     for (uint32_t b = w; b < nbV; b += group_waves())
     {
@@ -671,16 +679,39 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
         }
     }
     STAMP(2);
-    // hist[k] := dropped vertices still alive after plane k = sum_{f>k} hist[f]
     __syncthreads();
-    if (tid == 0)
-    {
-        uint32_t run = 0;
-        for (int k = (int)F - 1; k >= 0; --k) { const uint32_t h = sh.hist[k]; sh.hist[k] = run; run += h; }
-    }
-    __syncthreads();
-    STAMP(3);
     T.nS = n; T.nLive = n; T.hUsed = hsum;
+}
+
+// Pre-pass: builds the reduced solid of `in` for the planes sh.planes[0..F) in T.
+// bmask/bblk: one word / one (count, ring entries) pair per 64 input vertices (LDS or global).
+// capH_emit: ring entries available while the masks are still in use.
+// Returns 0 or SURTR_OVERFLOW (does not fit T) -- uniform over the workgroup.
+template <class TT>
+__device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh, unsigned long long* bmask, uint2* bblk,
+                       uint32_t capH_emit, unsigned long long* spill_mask, uint2* spill_blk)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
+    uint32_t n = 0, hsum = 0;
+    prepass_select(in, F, sh, bmask, bblk, T.aux0, T.aux2, n, hsum);
+    const bool toolong = TT::MAXLEN <= InLds::MAXLEN && sh.flagBad != 0;
+    __syncthreads();
+    if (spill_mask != nullptr && spill_mask != bmask)
+    {
+        // a global copy of the bit mask always exists (clip_planes' all-in-plane corner case reads it).  The LDS
+        // masks share the tail of the ring area; a band that needs all of it moves both mask arrays to global scratch.
+        const bool spill = hsum > capH_emit && hsum <= T.capH;
+        for (uint32_t b = tid; b < nbV; b += group_size()) { spill_mask[b] = bmask[b]; if (spill) spill_blk[b] = bblk[b]; }
+        __syncthreads();
+        if (spill) { bmask = spill_mask; bblk = spill_blk; capH_emit = T.capH; }
+    }
+    if (toolong) COUNT(32);
+    if (n > T.capV) COUNT(33);
+    if (hsum > capH_emit) COUNT(34);
+    if (toolong || n > T.capV || hsum > capH_emit || n >= TT::SENT) return SURTR_OVERFLOW;
+    prepass_emit(in, T, bmask, bblk, T.aux1, n, hsum);
+    prepass_finish_hist(F, sh);
     return 0;
 }
 
@@ -955,6 +986,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             }
         }
         uint32_t hend = T.hUsed + 3u * M;
+        if (tid == 0) sh.misc[6] = 0;      // length of the relink's chain list
         __syncthreads();
         STAMP(5);
 
@@ -964,20 +996,18 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         {
             // regular cap: every new vertex X=[cut, kept] finds its successor by walking the face
             // loop through clipped vertices; its final ring is [pred, succ, kept].
-            bool bad = false;
-            for (uint32_t t = tid; t < M; t += group_size())
-            {
-                const uint32_t X = n0 + t;
-                uint32_t prev = X, c = T.ring[T.loff[X]], steps = 0;
-                while (c < TT::SENT && T.comp[c] == -1 && steps++ < n1)
-                {
-                    const uint32_t hold = c;
-                    c = face_next(T.ring + T.loff[c], T.llen[c], prev);
-                    prev = hold;
-                }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-                atomicAdd(&g_stamp[40], (unsigned long long)steps); atomicAdd(&g_stamp[41], 1ull); atomicMax(&sh.misc[5], steps);
-#endif
+            //
+            // Most walks take 2-3 steps, but a plane that trims the cap of an earlier plane walks along that cap's
+            // boundary: one lane chases ~100 dependent ring reads while the workgroup waits.  So walks stop after
+            // SURTR_WALK0 steps; if any is unfinished, the runs of clipped cap vertices are collapsed by pointer
+            // jumping first.  A cap vertex c=[pred, succ, kept] entered from succ is left towards pred (the entry
+            // before succ), so along a run jump[c] -> pred while pred is again a clipped 3-ring entered from its succ
+            // slot; after the rounds jump[c] is a vertex further down the same run (the walk would have reached it,
+            // arriving from its succ slot), and the resumed walk takes the shortcut.  Results are those of the
+            // plain walk.
+            bool bad = false, longw = false;
+            uint32_t* wsave = T.aux1;      // keptof is dead after the patch
+            auto finish = [&](uint32_t t, uint32_t X, uint32_t c) {
                 if (c >= TT::SENT || c < n0 || c == X || T.comp[c] != 2) { bad = true; T.succ[t] = X; }
                 else
                 {
@@ -985,13 +1015,81 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     atomicAdd(&T.pcnt[c - n0], 1u);
                     T.pred[c - n0] = X;
                 }
+            };
+            for (uint32_t t = tid; t < M; t += group_size())
+            {
+                const uint32_t X = n0 + t;
+                uint32_t prev = X, c = T.ring[T.loff[X]], steps = 0;
+                while (c < TT::SENT && T.comp[c] == -1 && steps < SURTR_WALK0)
+                {
+                    const uint32_t hold = c;
+                    c = face_next(T.ring + T.loff[c], T.llen[c], prev);
+                    prev = hold; ++steps;
+                }
+                if (c < TT::SENT && T.comp[c] == -1) { wsave[t] = prev | 0x80000000u; T.succ[t] = c; longw = true; continue; }
+                wsave[t] = 0;
+                finish(t, X, c);
             }
+            if (longw) pf[7] = 1;
             if (bad) pf[4] = 1;
             __syncthreads();
             STAMP(12);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-            if (tid == 0) { atomicAdd(&g_stamp[42], (unsigned long long)sh.misc[5]); atomicAdd(&g_stamp[43], 1ull); atomicAdd(&g_stamp[44], (unsigned long long)((M + group_size() - 1) / group_size())); sh.misc[5] = 0; }
-#endif
+            COUNT(43);
+            if (pf[7] != 0)
+            {
+                COUNT(40);
+                uint32_t* jump = T.aux0; uint32_t* chain = T.aux2;     // idmap / cutcnt are dead here
+                for (uint32_t v = tid; v < n0; v += group_size())
+                {
+                    if (T.comp[v] != -1 || T.llen[v] != 3u) continue;
+                    const uint32_t p = T.ring[T.loff[v]];
+                    uint32_t j = v;
+                    if (p < TT::SENT && T.comp[p] == -1 && T.llen[p] == 3u)
+                    {
+                        const I* rp = T.ring + T.loff[p];
+                        if ((uint32_t)rp[1] == v && (uint32_t)rp[0] != v) j = p;     // entered from its succ slot only
+                    }
+                    jump[v] = j;
+                    if (j != v) chain[atomicAdd(&sh.misc[6], 1u)] = v;
+                }
+                __syncthreads();
+                const uint32_t L = sh.misc[6];
+                for (uint32_t round = 0; round < 6u && (1u << round) < L; ++round)
+                {
+                    // in place: whatever value a lane reads is a vertex further down the same run
+                    for (uint32_t i = tid; i < L; i += group_size())
+                    {
+                        const uint32_t v = chain[i], j = jump[v], jj = jump[j];
+                        if (jj != j) jump[v] = jj;
+                    }
+                    __syncthreads();
+                }
+                STAMP(11);
+                for (uint32_t t = tid; t < M; t += group_size())
+                {
+                    const uint32_t w0 = wsave[t];
+                    if (!(w0 & 0x80000000u)) continue;
+                    const uint32_t X = n0 + t;
+                    uint32_t prev = w0 & 0x7fffffffu, c = T.succ[t], steps = SURTR_WALK0;
+                    while (c < TT::SENT && T.comp[c] == -1 && steps++ < n1)
+                    {
+                        const I* r = T.ring + T.loff[c];
+                        const uint32_t len = T.llen[c];
+                        if (len == 3u && (uint32_t)r[1] == prev && (uint32_t)r[0] != prev)
+                        {
+                            const uint32_t e = jump[c];
+                            if (e != c) { c = e; prev = T.ring[T.loff[e] + 1u]; continue; }
+                        }
+                        const uint32_t hold = c;
+                        c = face_next(r, len, prev);
+                        prev = hold;
+                    }
+                    finish(t, X, c);
+                }
+                if (bad) pf[4] = 1;
+                __syncthreads();
+                STAMP(14);
+            }
             bad = false;
             for (uint32_t t = tid; t < M; t += group_size()) if (T.pcnt[t] != 1u) bad = true;
             if (bad) pf[4] = 1;
