@@ -93,9 +93,10 @@ int surtr_set_arena(surtr_ctx* ctx, uint64_t verts, uint64_t nbrs, uint64_t idx)
 
 /* Per-kernel timing with HIP events recorded on the work stream (the reference's TIMER_* phase
  * timers, Inc/pch.h:122-141, Src/Surtr.cpp:1917-1941).  ms[i] = duration of the last launch of
- * 0 clip_pairs (Mesh), 1 frag_table, 2 refit, 3 faces, 4 out_scan, 5 pack, 6 clip_convex; -1 where not run. */
+ * 0 clip_pairs (Mesh), 1 frag_table, 2 refit, 3 faces, 4 out_scan, 5 pack, 6 clip_convex, 7 prep_pairs,
+ * 8 clip_pairs_big (runs beside clip_pairs on an internal stream); -1 where not run. */
 int surtr_set_profiling(surtr_ctx* ctx, int on);
-int surtr_kernel_times(surtr_ctx* ctx, float ms[8]);
+int surtr_kernel_times(surtr_ctx* ctx, float ms[16]);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Replaces compound.PieceVec (Inc/Surtr.h:113-134): n pieces, each a (Convex, Mesh)

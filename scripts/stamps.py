@@ -10,7 +10,7 @@ eng = E.Engine(0)
 eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = eng.fracture_event(0, 4096, flags=flags)
-buf = (ctypes.c_ulonglong * 48)()
+buf = (ctypes.c_ulonglong * 80)()
 L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
@@ -26,4 +26,6 @@ print("regular (parallel-relink) planes: %d, with chain jumping: %d" % (buf[43],
 print("prepass (big solids): undecided blocks %d of %d (%.1f%%), needy vertices %d" % (buf[45], buf[46], 100.0*buf[45]/max(buf[46],1), buf[47]))
 print("pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[21 + i] for i in range(11)])
 print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[18], 1), buf[17], buf[18]))
+print("big kernel: pair cost histogram:", [buf[51 + i] for i in range(10)])
+print("big kernel: per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[48] / max(buf[50], 1), buf[49], buf[50]))
 eng.close()

@@ -51,7 +51,7 @@
 // Diagnostic build only (-DSURTR_STAMP): lane 0 accumulates s_memtime deltas per phase into a
 // global table that no product code reads.
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-__device__ unsigned long long g_stamp[48];
+__device__ unsigned long long g_stamp[80];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
 #define STAMP(i) do { if (threadIdx.x == 0 && blockDim.x > 64) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); st_t0 = st_t1; } } while (0)
 #define COUNT(i) do { if (threadIdx.x == 0 && blockDim.x > 64) atomicAdd(&g_stamp[i], 1ull); } while (0)
@@ -363,6 +363,7 @@ __device__ void collapse_serial(Topo<TT>& T, uint32_t n1)
 //                   hsum ring entries; sh.flagBad = a kept vertex has more neighbours than a narrow ring may hold
 //   prepass_emit    writes the reduced solid into T (any memory)
 // needy/und: u32 work lists (V and V/64 entries).
+template <int G, int NB>
 __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared& sh, unsigned long long* bmask, uint2* bblk,
                                       uint32_t* needy, uint32_t* und, uint32_t& n_out, uint32_t& hsum_out)
 {
@@ -427,14 +428,14 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
         if (tid == 0 && V > 10000u) { atomicAdd(&g_stamp[45], (unsigned long long)nWork); atomicAdd(&g_stamp[46], (unsigned long long)nbV); }
 #endif
     }
-    for (uint32_t b0 = w; b0 < nWork; b0 += 4u * group_waves())
+    for (uint32_t b0 = w; b0 < nWork; b0 += (uint32_t)G * group_waves())
     {
-        // four 64-blocks per wave iteration: their loads are in flight together, and every plane fetched
+        // G (four) 64-blocks per wave iteration: their loads are in flight together, and every plane fetched
         // from LDS is applied to all four (planes outermost: one LDS fetch per plane, four independent chains)
-        float px4[4], py4[4], pz4[4], rv4[4], mag4[4];
-        uint32_t f4[4], id4[4]; bool done4[4], clear4[4], valid4[4];
+        float px4[G], py4[G], pz4[G], rv4[G], mag4[G];
+        uint32_t f4[G], id4[G]; bool done4[G], clear4[G], valid4[G];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < G; ++g)
         {
             const uint32_t wb = b0 + g * group_waves();
             const uint32_t blk = (sorted && wb < nWork) ? und[wb] : wb;
@@ -455,14 +456,16 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < G; ++g)
         {
             mag4[g] = fabsf(px4[g]) + fabsf(py4[g]) + fabsf(pz4[g]);
             f4[g] = 0xFFu; done4[g] = !valid4[g]; clear4[g] = rv4[g] >= 0.f;
         }
         for (uint32_t k = 0; k < F; ++k)
         {
-            const bool all_done = done4[0] && done4[1] && done4[2] && done4[3];
+            bool all_done = true;
+#pragma unroll
+            for (int g = 0; g < G; ++g) all_done = all_done && done4[g];
 #ifndef SURTR_EMUL
             if (__all(all_done)) break;
 #else
@@ -471,7 +474,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             const float4 pk = sh.planes[k];
             const float4 mk = sh.pmar[k];
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < G; ++g)
             {
                 if (done4[g]) continue;
                 const float sk = plane_dist(pk, px4[g], py4[g], pz4[g]);
@@ -481,7 +484,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < G; ++g)
         {
             const uint32_t wb = b0 + g * group_waves();
             if (wb >= nWork) break;
@@ -539,19 +542,19 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
                     if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
                 return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
             };
-            for (uint32_t j0 = 0; j0 < deg && !keep; j0 += 8)
+            for (uint32_t j0 = 0; j0 < deg && !keep; j0 += NB)
             {
-                int32_t u[8]; float ux[8], uy[8], uz[8];
+                int32_t u[NB]; float ux[NB], uy[NB], uz[NB];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
+                for (int q = 0; q < NB; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < NB; ++q)
                 {
                     const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
                     ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < NB; ++q)
                     if (u[q] >= 0 && !same_fc(ux[q], uy[q], uz[q])) keep = true;
             }
             if (!keep && !(in.tri != nullptr && in.tri[v]))
@@ -694,7 +697,7 @@ __device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& 
     const uint32_t tid = threadIdx.x;
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
     uint32_t n = 0, hsum = 0;
-    prepass_select(in, F, sh, bmask, bblk, T.aux0, T.aux2, n, hsum);
+    prepass_select<4, 8>(in, F, sh, bmask, bblk, T.aux0, T.aux2, n, hsum);
     const bool toolong = TT::MAXLEN <= InLds::MAXLEN && sh.flagBad != 0;
     __syncthreads();
     if (spill_mask != nullptr && spill_mask != bmask)
@@ -794,17 +797,18 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         uint32_t* pf = sh.pf[it % 3u];
         // ---- classify (:307-318) ----
         {
-            bool anyc = false, anyk = false, anyz = false;
+            bool anyc = false, anyk = false; uint32_t zlen = 0;
             for (uint32_t v = tid; v < nS; v += group_size())
             {
                 if (T.comp[v] == SURTR_DEAD) continue;
                 const int c = side_of(plane_dist(pl, T.pos[3 * v], T.pos[3 * v + 1], T.pos[3 * v + 2]));
                 T.comp[v] = (int8_t)c;
-                anyc |= c < 0; anyk |= c > 0; anyz |= c == 0;
+                anyc |= c < 0; anyk |= c > 0;
+                if (c == 0) zlen += 1u + (uint32_t)T.llen[v];
             }
             if (anyc) pf[0] = 1;
             if (anyk) pf[1] = 1;
-            if (anyz) pf[2] = 1;
+            if (zlen) atomicAdd(&pf[2], zlen);      // in-plane vertices: nonzero = any, value = their ring entries (+1 each)
         }
         __syncthreads();
         if (tid == 0) { uint32_t* nx = sh.pf[(it + 2u) % 3u]; for (int q = 0; q < 8; ++q) nx[q] = 0; }
@@ -891,10 +895,22 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         uint32_t M = 0, nCut = 0;
         scan_blocks(nS, T.blk, sh, cutfn, M, nCut);
         STAMP(8);
-        if (nS + M > T.capV || T.hUsed + 3u * M + (anyZero ? T.hUsed : 0u) > T.capH || nS + M >= TT::SENT)
+        // An in-plane plane takes the serial relink, which re-homes the rings of in-plane vertices (room for the walks
+        // that arrive + the old_neighbors snapshot): about 4 entries per ring entry of an in-plane vertex.  New vertices
+        // reached by several walks (degenerate rings) need room too; the exact demand is checked once it is known
+        // (SURTR_OVERFLOW below), this estimate only decides whether to squeeze first.
+        const uint32_t zroom = anyZero ? 4u * pf[2] + 64u : 0u;
+        if (nS + M > T.capV || T.hUsed + 3u * M + zroom > T.capH || nS + M >= TT::SENT)
         {
             // out of slots: squeeze the tombstones out (order-preserving, like :464-495) and retry this plane once
-            if (squeezed) { COUNT(36); return SURTR_OVERFLOW; }
+            if (squeezed)
+            {
+                COUNT(36);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+                if (tid == 0) printf("overflow after squeeze: plane %u of %u, nS %u + M %u (capV %u), hUsed %u + 3M (capH %u), nLive %u\n", k, F, nS, M, T.capV, T.hUsed, T.capH, T.nLive);
+#endif
+                return SURTR_OVERFLOW;
+            }
             squeeze(T, sh, tmp);
             squeezed = true;
             --k;

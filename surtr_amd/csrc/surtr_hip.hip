@@ -3,7 +3,9 @@
 // Event pipeline (all on the caller's HIP stream, inputs resident in HBM):
 //   k_place_cells   A3   Polygon3D::Scale/Translate + ConstructFacePlane      (Src/VMACH.cpp:302-310, 506-534)
 //   k_clip_convex   A7   Convex of every (cell, piece) pair, one wave per task (Src/Surtr.cpp:1466-1468)
-//   k_clip_pairs    A7+A8+A11  Mesh of every pair whose Convex survived: clip, label islands,
+//   k_prep_pairs    A7   pre-pass of the Mesh of every pair whose Convex survived: the vertices the planes can touch,
+//                        left in HBM in the layout of the LDS topology
+//   k_clip_pairs(_big)  A7+A8+A11  Mesh of those pairs: plane loop on the reduced solid, label islands,
 //                        park the result in the arena                          (Src/Surtr.cpp:1470-1504, Src/Poly.cpp:265-500)
 //   k_frag_table    A11  cell-major fragment table                             (Src/Surtr.cpp:2133-2146)
 //   k_refit         A12  limit-4 hull normals + k-DOP slabs + clip Convex      (Src/Surtr.cpp:1449-1455)
@@ -33,8 +35,38 @@ struct PairRec
     uint32_t cv_off, cv_n, ch_off, ch_n;   // clipped Convex in the arena
     uint32_t mv_off, mv_n, mh_off, mh_n;   // clipped Mesh (all islands, island-major)
     uint32_t ni, isl_off;                  // islands and where their (nv, nh) records start
-    uint32_t status, pad;
+    uint32_t status;
+    // reduced Mesh left in HBM by k_prep_pairs: img_fmt = IMG_*, offset in 16-byte units, vertices, ring entries
+    uint32_t img_fmt, img_off, img_n, img_h, pad;
 };
+
+enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
+       IMG_NARROW = 1,    // 16-bit image, loads straight into the LDS topology
+       IMG_WIDE = 2,      // the reduced solid does not fit the LDS topology: k_clip_pairs goes to global scratch directly
+       IMG_EMPTY = 3 };   // nothing of the Mesh is left
+
+// Byte offsets of the sections of one image (all 16-byte aligned): hist/zhist (F words each), the keep mask
+// (one word per 64 input vertices), then the reduced solid in the LDS layout, then its positions.
+struct ImgLayout { uint32_t hist, zhist, mask, loff, llen, comp, ring, pos, total; };
+__host__ __device__ static inline ImgLayout img_layout(uint32_t F, uint32_t nbV, uint32_t n, uint32_t hsum)
+{
+    auto up = [](uint32_t b) { return (b + 15u) & ~15u; };
+    ImgLayout L;
+    L.hist = 0; L.zhist = up(4u * F); L.mask = L.zhist + up(4u * F); L.loff = L.mask + up(8u * nbV);
+    L.llen = L.loff + up(2u * n); L.comp = L.llen + up(n); L.ring = L.comp + up(n); L.pos = L.ring + up(2u * hsum);
+    L.total = L.pos + up(12u * n);
+    return L;
+}
+
+struct ImgArena { char* base; uint32_t cap16; };      // capacity in 16-byte units; cursor = Arena::cursors[10]
+
+// Per-workgroup scratch of k_prep_pairs: work lists of the pre-pass and (for very large solids) its masks.
+struct PrepPool { char* base; size_t per_wg; uint32_t VMAX; };
+static size_t prep_bytes_per_wg(uint32_t VMAX)
+{
+    auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_LANES + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
+}
 
 struct FragRec
 {
@@ -51,7 +83,9 @@ struct Arena
     float* pos; uint32_t* loff; uint32_t* llen; int32_t* nbr; uint32_t* idx;
     uint2* isl;
     uint32_t capV, capH, capI, capIsl;
-    uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=work queue [5]=status [6]=work queue 2 [7]=work queue 3
+    uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=clip queue [5]=status [6]=refit queue [7]=faces queue [8]=convex queue
+                         // [9]=pre-pass queue [10]=image arena (16-byte units) [11]=big clip queue
+                         // [16..31]=pairs per cost class (k_prep_pairs)
 };
 
 struct Pieces
@@ -128,11 +162,41 @@ struct LdsTopoT
     uint16_t ring[LH];
 };
 typedef LdsTopoT<SURTR_LV, SURTR_LH> LdsTopo;          // Mesh solids: two workgroups of 256 threads per CU
+typedef LdsTopoT<2 * SURTR_LV, 2 * SURTR_LH> LdsTopoBig;   // the few Mesh solids with a large band: one workgroup per CU
 #ifdef SURTR_EMUL
 typedef LdsTopoT<64, 512> LdsTopoSmall;                 // (emulation: small enough to exercise the fallback too)
 #else
 typedef LdsTopoT<512, 4096> LdsTopoSmall;               // Convex solids: one wave per task, many tasks per CU
 #endif
+
+template <class LT>
+__device__ static Topo<InLds> lds_topo(Scratch& S, LT& L)
+{
+    Topo<InLds> T;
+    T.loff = L.loff; T.llen = L.llen; T.comp = L.comp; T.ring = L.ring; T.pos = S.pos;
+    T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = L.blk;
+    T.capV = LT::kLV < S.CV ? LT::kLV : S.CV; T.capH = LT::kLH;
+    T.nS = T.nLive = T.hUsed = 0;
+    return T;
+}
+
+// The wide variant on global scratch: pre-pass + plane loop.  Returns 0 or an error code.
+template <class Consume>
+__device__ static int clip_global(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, Consume consume)
+{
+    COUNT(20);
+    Topo<InGlobal> T;
+    T.loff = S.g_loff; T.llen = S.g_llen; T.comp = S.g_comp; T.ring = S.g_ring; T.pos = S.pos;
+    T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = S.blk;
+    T.capV = S.CV; T.capH = S.CH;
+    T.nS = T.nLive = T.hUsed = 0;
+    int rc = prepass(in, F, T, sh, S.gmask, S.gblk, S.CH, nullptr, nullptr);
+    if (rc == 0) { __syncthreads(); rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring}); }
+    __syncthreads();
+    if (rc == SURTR_OVERFLOW) return SURTR_E_CAPACITY;
+    if (rc != 0) return rc;
+    return consume(T);
+}
 
 // Clips `in` by sh.planes[0..F) and hands the resulting Topo (nLive == 0: empty) to `consume`.
 // Returns 0 or an error code (uniform over the workgroup).
@@ -142,11 +206,7 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
     int rc;
     {
-        Topo<InLds> T;
-        T.loff = L.loff; T.llen = L.llen; T.comp = L.comp; T.ring = L.ring; T.pos = S.pos;
-        T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = L.blk;
-        T.capV = LT::kLV < S.CV ? LT::kLV : S.CV; T.capH = LT::kLH;
-        T.nS = T.nLive = T.hUsed = 0;
+        Topo<InLds> T = lds_topo(S, L);
         // pre-pass masks sit in the tail of the ring area while the reduced solid is being emitted
         // (the tail is free again afterwards); a copy of the bit mask goes to global scratch for the
         // all-in-plane corner case of clip_planes
@@ -167,18 +227,43 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
         if (rc == 0) return consume(T);
     }
     if (rc != SURTR_OVERFLOW) return rc;
-    COUNT(20);
-    Topo<InGlobal> T;
-    T.loff = S.g_loff; T.llen = S.g_llen; T.comp = S.g_comp; T.ring = S.g_ring; T.pos = S.pos;
-    T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.blk = S.blk;
-    T.capV = S.CV; T.capH = S.CH;
-    T.nS = T.nLive = T.hUsed = 0;
-    rc = prepass(in, F, T, sh, S.gmask, S.gblk, S.CH, nullptr, nullptr);
-    if (rc == 0) { __syncthreads(); rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring}); }
-    __syncthreads();
-    if (rc == SURTR_OVERFLOW) return SURTR_E_CAPACITY;
-    if (rc != 0) return rc;
-    return consume(T);
+    return clip_global(in, F, S, sh, consume);
+}
+
+// The same from an image of the reduced solid (k_prep_pairs ran the pre-pass): load it into the LDS topology,
+// run the plane loop; a solid that outgrows the LDS topology is redone on global scratch from the input.
+template <class LT, class Consume>
+__device__ static int clip_image(const char* img, uint32_t n, uint32_t hsum, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
+                                 LT& L, Consume consume)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
+    const ImgLayout lay = img_layout(F, nbV, n, hsum);
+    Topo<InLds> T = lds_topo(S, L);
+    int rc = SURTR_OVERFLOW;
+    if (n <= T.capV && hsum <= T.capH)
+    {
+        const uint32_t* hs = (const uint32_t*)(img + lay.hist); const uint32_t* zs = (const uint32_t*)(img + lay.zhist);
+        for (uint32_t k = tid; k < F; k += group_size()) { sh.hist[k] = hs[k]; sh.zhist[k] = zs[k]; }
+        if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; }
+        // sections are padded to 16 bytes and the LDS arrays to a multiple of 4 entries: copy whole words
+        auto copy_words = [&](void* dst, const void* src, uint32_t bytes) {
+            uint32_t* d = (uint32_t*)dst; const uint32_t* q = (const uint32_t*)src;
+            for (uint32_t i = tid; i < (bytes + 3u) / 4u; i += group_size()) d[i] = q[i];
+        };
+        copy_words(L.loff, img + lay.loff, 2u * n);
+        copy_words(L.llen, img + lay.llen, n);
+        copy_words(L.comp, img + lay.comp, n);
+        copy_words(L.ring, img + lay.ring, 2u * hsum);
+        copy_words(S.pos, img + lay.pos, 12u * n);
+        T.nS = n; T.nLive = n; T.hUsed = hsum;
+        __syncthreads();
+        rc = clip_planes(T, F, sh, in, (const unsigned long long*)(img + lay.mask), SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
+        __syncthreads();
+        if (rc == 0) return consume(T);
+    }
+    if (rc != SURTR_OVERFLOW) return rc;
+    return clip_global(in, F, S, sh, consume);
 }
 
 // ------------------------------------------------------------- small helpers
@@ -414,20 +499,120 @@ __global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const flo
     }
 }
 
+// -------------------------------------------------------------- k_prep_pairs
+// Pre-pass of the Mesh of every pair whose Convex survived, as a kernel of its own: it needs no LDS topology, so
+// several workgroups share a CU and hide each other's gather latency.  The reduced solid goes to HBM as an
+// "image" in the layout of the LDS topology; k_clip_pairs loads it with plain copies.  Pairs this kernel leaves
+// alone (small solids, image arena full) are pre-passed by k_clip_pairs itself.
+#ifdef SURTR_EMUL
+#define SURTR_PREP_MINV 48u
+#else
+#define SURTR_PREP_MINV 1024u
+#endif
+#define SURTR_PREP_NB 1024u         // 64-vertex blocks whose masks fit this kernel's LDS (65536 vertices)
+#ifndef SURTR_PREP_WAVES
+#define SURTR_PREP_WAVES 6
+#endif
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV,
+                                                         PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                                         uint32_t* __restrict__ order)
+{
+    // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
+    // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
+    auto enqueue = [&](uint32_t p, uint32_t cls) { order[(size_t)cls * n_pairs + atomicAdd(&A.cursors[16u + cls], 1u)] = p; };
+    __shared__ Shared sh;
+    __shared__ unsigned long long lmask[SURTR_PREP_NB];
+    __shared__ uint2 lblk[SURTR_PREP_NB];
+    const uint32_t tid = threadIdx.x;
+    char* sp = pool.base + (size_t)blockIdx.x * pool.per_wg;
+    auto take = [&](size_t bytes) { char* r = sp; sp += (bytes + 255) & ~(size_t)255; return r; };
+    uint32_t* needy = (uint32_t*)take((size_t)pool.VMAX * 4);
+    uint32_t* orig = (uint32_t*)take((size_t)pool.VMAX * 4);
+    uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 4);
+    unsigned long long* gmask = (unsigned long long*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
+    uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[9], 1u);
+        __syncthreads();
+        const uint32_t p = sh.misc[7];
+        if (p >= n_pairs) break;
+        if (pairs[p].cv_n == 0 || pairs[p].status != 0) continue;
+        const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
+        const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
+        const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
+        if (V < SURTR_PREP_MINV || V > pool.VMAX) { if (tid == 0) enqueue(p, V > pool.VMAX ? 13u : 0u); continue; }
+        const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
+        for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
+        __syncthreads();
+        SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, V, P.mtri + m0, P.mrad + m0,
+                    P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+        const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
+        unsigned long long* bmask = nbV <= SURTR_PREP_NB ? lmask : gmask;
+        uint2* bblk = nbV <= SURTR_PREP_NB ? lblk : gblk;
+        uint32_t n = 0, hsum = 0;
+#ifndef SURTR_PREP_G
+#define SURTR_PREP_G 2
+#define SURTR_PREP_NBATCH 4
+#endif
+        prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
+        const bool toolong = sh.flagBad != 0;
+        __syncthreads();
+        uint32_t fmt = IMG_NARROW, off16 = 0;
+        if (n == 0) fmt = IMG_EMPTY;
+        else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
+        const ImgLayout lay = img_layout(F, nbV, n, hsum);
+        if (fmt == IMG_NARROW)
+        {
+            const uint32_t need16 = lay.total / 16u;
+            if (tid == 0) sh.misc[0] = atomicAdd(&A.cursors[10], need16);
+            __syncthreads();
+            off16 = sh.misc[0];
+            __syncthreads();
+            if ((uint64_t)off16 + need16 > IA.cap16) fmt = IMG_NONE;      // arena full: k_clip_pairs does this pair alone
+        }
+        if (fmt == IMG_NARROW)
+        {
+            char* img = IA.base + (size_t)off16 * 16u;
+            prepass_finish_hist(F, sh);
+            uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist);
+            for (uint32_t k = tid; k < F; k += group_size()) { hs[k] = sh.hist[k]; zs[k] = sh.zhist[k]; }
+            unsigned long long* gm = (unsigned long long*)(img + lay.mask);
+            for (uint32_t b = tid; b < nbV; b += group_size()) gm[b] = bmask[b];
+            Topo<InLds> T;
+            T.loff = (uint16_t*)(img + lay.loff); T.llen = (uint8_t*)(img + lay.llen); T.comp = (int8_t*)(img + lay.comp);
+            T.ring = (uint16_t*)(img + lay.ring); T.pos = (float*)(img + lay.pos);
+            T.succ = T.pred = T.pcnt = T.aux0 = T.aux1 = T.aux2 = nullptr; T.blk = nullptr;
+            T.capV = n; T.capH = hsum; T.nS = T.nLive = T.hUsed = 0;
+            prepass_emit(min, T, bmask, bblk, orig, n, hsum);
+        }
+        if (tid == 0)
+        {
+            pairs[p].img_fmt = fmt; pairs[p].img_off = off16; pairs[p].img_n = n; pairs[p].img_h = hsum;
+            // classes 14 and 15 go to k_clip_pairs_big: bands that leave the regular LDS topology little room to grow
+            // (the first plane alone may add a thousand vertices), and solids beyond any LDS topology
+            uint32_t cls = 15u;
+            if (fmt == IMG_NONE) cls = 13u;
+            else if (fmt == IMG_NARROW)
+                cls = (n + capV / 5u > capV || hsum + SURTR_LH / 6u > SURTR_LH) ? 14u : 1u + (n >> 9 < 12u ? n >> 9 : 12u);
+            if (fmt != IMG_EMPTY) enqueue(p, cls);
+        }
+    }
+}
+
 // -------------------------------------------------------------- k_clip_pairs
 // Mesh of every pair whose Convex survived (:1470-1500): clip, islands, island-major copy to the arena.
-#ifndef SURTR_CLIP_MINWAVES
-#define SURTR_CLIP_MINWAVES 1
-#endif
-__global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
-                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
-                                                         uint32_t n_pairs,
-                                                         ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
-                                                         const uint2* __restrict__ pair_list)
+// One workgroup: pairs of cost classes cls_hi..cls_lo, heavy first (tickets from A.cursors[qcur]).
+template <class LT>
+__device__ static void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Pieces& P, const float4* __restrict__ planes,
+                                       const uint32_t* __restrict__ plane_off, uint32_t cell_begin, uint32_t n_pairs,
+                                       const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
+                                       const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                       int cls_hi, int cls_lo, uint32_t qcur)
 {
-    __shared__ Shared sh;
-    __shared__ LdsTopo L;
-    Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
@@ -435,12 +620,24 @@ __global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pi
     while (true)
     {
         __syncthreads();
-        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[4], 1u);
+        if (tid == 0)
+        {
+            // next ticket -> pair (k_prep_pairs filled `order`)
+            uint32_t t = atomicAdd(&A.cursors[qcur], 1u), p = 0xFFFFFFFFu;
+            for (int cls = cls_hi; cls >= cls_lo; --cls)
+            {
+                const uint32_t cnt = A.cursors[16 + cls];
+                if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
+                t -= cnt;
+            }
+            sh.misc[7] = p;
+        }
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
         PairRec rec = pairs[p];
         if (rec.cv_n == 0 || rec.status != 0) continue;       // empty Convex: the Mesh is not clipped (:1467-1468)
+        if (rec.img_fmt == IMG_EMPTY) continue;               // the pre-pass kernel found nothing left of the Mesh
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
@@ -452,20 +649,51 @@ __global__ __launch_bounds__(SURTR_WG, SURTR_CLIP_MINWAVES) void k_clip_pairs(Pi
         const uint32_t m0 = P.mvo[piece];
         SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
                     P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
-        int err = clip_any(min, F, S, sh, L, [&](auto& T) -> int {
+        auto consume = [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_mesh_islands(T, sh, A, rec);
-        });
+        };
+        int err;
+        if (rec.img_fmt == IMG_NARROW) err = clip_image(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+        else if (rec.img_fmt == IMG_WIDE) err = clip_global(min, F, S, sh, consume);
+        else err = clip_any(min, F, S, sh, L, consume);
         __syncthreads();
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[21 + bkt], 1ull); }
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[(cls_hi == 15 ? 51 : 21) + bkt], 1ull); }
 #endif
     }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp[16], d); atomicMax(&g_stamp[17], d); atomicAdd(&g_stamp[18], 1ull); }
+    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; const int o = cls_hi == 15 ? 48 : 16; atomicAdd(&g_stamp[o], d); atomicMax(&g_stamp[o + 1], d); atomicAdd(&g_stamp[o + 2], 1ull); }
 #endif
+}
+
+__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order)
+{
+    __shared__ Shared sh;
+    __shared__ LdsTopo L;
+    Scratch S = carve(pool, blockIdx.x);
+    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, 13, 0, 4u);
+}
+
+// The same with the double-size LDS topology (one workgroup per CU) for cost classes 14 and 15; runs beside
+// k_clip_pairs on a second stream.  Its workgroups use the scratch slots after those of k_clip_pairs.
+__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const float4* __restrict__ planes,
+                                                             const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                             uint32_t n_pairs,
+                                                             ScratchPool pool, uint32_t wg_base, Arena A, ImgArena IA,
+                                                             PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                                             const uint32_t* __restrict__ order)
+{
+    __shared__ Shared sh;
+    __shared__ LdsTopoBig L;
+    Scratch S = carve(pool, wg_base + blockIdx.x);
+    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, 15, 14, 11u);
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -1232,7 +1460,15 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
 struct surtr_ctx
 {
     int device = 0;
-    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048;
+    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1536;
+    PrepPool prep{nullptr, 0, 0}; uint32_t n_wg_prep = 0;
+    ImgArena img{nullptr, 0};
+    uint32_t* d_order = nullptr; uint32_t cap_order = 0;
+    uint32_t n_wg_big = 64;          // workgroups of k_clip_pairs_big
+#ifndef SURTR_EMUL
+    hipStream_t stream2 = nullptr;   // k_clip_pairs_big runs beside k_clip_pairs
+    hipEvent_t ev_prep = nullptr, ev_big = nullptr;
+#endif
     hipStream_t stream = nullptr;
     std::string err;
     // pieces
@@ -1271,17 +1507,21 @@ struct surtr_ctx
     // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
     bool profiling = false;
 #ifndef SURTR_EMUL
-    hipEvent_t ev[16] = {};     // begin/end per kernel slot 0..7
+    hipEvent_t ev[32] = {};     // begin/end per kernel slot 0..15
 #endif
-    bool ev_valid[8] = {};
+    bool ev_valid[16] = {};
 };
 
 #ifndef SURTR_EMUL
-#define PROF_BEGIN(i) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], st); } } while (0)
-#define PROF_END(i) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], st); ctx->ev_valid[i] = true; } } while (0)
+#define PROF_BEGIN_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], strm); } } while (0)
+#define PROF_END_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], strm); ctx->ev_valid[i] = true; } } while (0)
+#define PROF_BEGIN(i) PROF_BEGIN_ON(i, st)
+#define PROF_END(i) PROF_END_ON(i, st)
 #else
 #define PROF_BEGIN(i) do { } while (0)
 #define PROF_END(i) do { } while (0)
+#define PROF_BEGIN_ON(i, strm) do { } while (0)
+#define PROF_END_ON(i, strm) do { } while (0)
 #endif
 
 #define HIPCHK(call)                                                                              \
@@ -1328,10 +1568,20 @@ int surtr_create(int device, surtr_ctx** out)
             ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
             ctx->max_wg_faces = (uint32_t)prop.multiProcessorCount * 4u;
             ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * 8u;
+            uint32_t prep_per_cu = 6u;
+            if (const char* e = getenv("SURTR_PREP_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) prep_per_cu = (uint32_t)v; }
+            ctx->max_wg_prep = (uint32_t)prop.multiProcessorCount * prep_per_cu;
         }
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-    if (hipMalloc((void**)&ctx->arena.cursors, 64) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+    if (hipMalloc((void**)&ctx->arena.cursors, 256) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+#ifndef SURTR_EMUL
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);     // its few large workgroups should be placed before k_clip_pairs fills the CUs
+    if (hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+#endif
     *out = ctx;
     return SURTR_OK;
 }
@@ -1348,6 +1598,13 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order);
+#ifndef SURTR_EMUL
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+    if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
+    for (int i = 0; i < 32; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+#endif
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
     free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
@@ -1679,6 +1936,37 @@ static int ensure_scratch_small(surtr_ctx* ctx, uint32_t n_wg)
     return SURTR_OK;
 }
 
+// Scratch of k_prep_pairs and the arena its images go to.  An image is at most the LDS topology plus masks; when the
+// arena runs out, k_clip_pairs pre-passes the remaining pairs itself, so its size only matters for speed.
+static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
+{
+    const uint32_t VMAX = std::max(ctx->vmax, 64u);
+    if (!(ctx->prep.base && ctx->prep.VMAX >= VMAX && ctx->n_wg_prep >= n_wg))
+    {
+        free_dev(ctx->prep.base); ctx->prep.base = nullptr;
+        ctx->prep.VMAX = VMAX; ctx->prep.per_wg = prep_bytes_per_wg(VMAX); ctx->n_wg_prep = n_wg;
+        HIPCHK(hipMalloc((void**)&ctx->prep.base, ctx->prep.per_wg * n_wg));
+    }
+    if (ctx->cap_order < n_pairs)
+    {
+        free_dev(ctx->d_order); ctx->d_order = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 16 * 4));
+        ctx->cap_order = n_pairs;
+    }
+    const uint64_t full = (uint64_t)ctx->vmax * 16 + (uint64_t)ctx->hmax * 2;
+    const uint64_t lds = (uint64_t)SURTR_LV * 16 + (uint64_t)SURTR_LH * 2;
+    const uint64_t per_pair = std::min(full, lds) + ctx->vmax / 8 + 2048;
+    uint64_t bytes = std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_pairs * per_pair, 1ull << 20), 4ull << 30);
+    const uint32_t cap16 = (uint32_t)(bytes / 16);
+    if (!(ctx->img.base && ctx->img.cap16 >= cap16))
+    {
+        free_dev(ctx->img.base); ctx->img.base = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->img.base, (size_t)cap16 * 16));
+        ctx->img.cap16 = cap16;
+    }
+    return SURTR_OK;
+}
+
 static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
 {
     // Result sizes are data dependent; the default reserves the whole input once per 8 pairs plus slack.
@@ -1724,15 +2012,19 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     (void)hipSetDevice(ctx->device);
     const uint32_t max_wg = ctx->max_wg;
     const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
-    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(n_wg, ctx->n_wg));
+    // scratch slots [0, max_wg) belong to k_clip_pairs, the n_wg_big after them to k_clip_pairs_big
+    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(max_wg + ctx->n_wg_big, ctx->n_wg));
     if (rc) return rc;
     const uint32_t n_wg_small = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_small));
     rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
     if (rc) return rc;
     rc = ensure_arena(ctx, std::max(n_pairs, 1u));
     if (rc) return rc;
+    const uint32_t n_wg_prep = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_prep));
+    rc = ensure_prep(ctx, std::max(n_pairs, 1u), std::max(n_wg_prep, ctx->n_wg_prep));
+    if (rc) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 64, st));
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 256, st));
     HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
     const uint8_t* d_out = nullptr;
     if (outside)
@@ -1742,17 +2034,38 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     }
     Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad, ctx->d_mperm, ctx->d_mpos_s, ctx->d_mrad_s, ctx->d_mbsph, ctx->d_mbo,
              ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->d_cperm, ctx->d_cpos_s, ctx->d_crad_s, ctx->d_cbsph, ctx->d_cbo, ctx->n_pieces};
-    for (int i = 0; i < 8; ++i) ctx->ev_valid[i] = false;
+    for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     PROF_BEGIN(6);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list);
     PROF_END(6);
+    PROF_BEGIN(7);
+    if (n_pairs)
+        hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), ctx->d_pairs, d_pair_list, ctx->d_order);
+    PROF_END(7);
+#ifndef SURTR_EMUL
+    hipStream_t st2 = ctx->stream2;
+    HIPCHK(hipEventRecord(ctx->ev_prep, st));
+    HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
+#else
+    hipStream_t st2 = st;
+#endif
+    PROF_BEGIN_ON(8, st2);
+    if (n_pairs)
+        hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st2, P, ctx->d_planes,
+                           ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
+    PROF_END_ON(8, st2);
     PROF_BEGIN(0);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->pool, ctx->arena, ctx->d_pairs, d_pair_list);
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
     PROF_END(0);
+#ifndef SURTR_EMUL
+    HIPCHK(hipEventRecord(ctx->ev_big, st2));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
+#endif
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
                        ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list);
@@ -1901,10 +2214,10 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
 }
 
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-int surtr_debug_stamps(unsigned long long out[48], int reset)
+int surtr_debug_stamps(unsigned long long out[80], int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 48) != hipSuccess) return SURTR_E_HIP;
-    if (reset) { unsigned long long z[48] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 80) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[80] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
     return SURTR_OK;
 }
 #endif
@@ -1915,20 +2228,20 @@ int surtr_set_profiling(surtr_ctx* ctx, int on)
 #ifndef SURTR_EMUL
     (void)hipSetDevice(ctx->device);
     if (on && !ctx->ev[0])
-        for (int i = 0; i < 16; ++i) HIPCHK(hipEventCreate(&ctx->ev[i]));
+        for (int i = 0; i < 32; ++i) HIPCHK(hipEventCreate(&ctx->ev[i]));
 #endif
     ctx->profiling = on != 0;
     return SURTR_OK;
 }
 
-int surtr_kernel_times(surtr_ctx* ctx, float ms[8])
+int surtr_kernel_times(surtr_ctx* ctx, float ms[16])
 {
     if (!ctx || !ms) return SURTR_E_INVALID;
-    for (int i = 0; i < 8; ++i) ms[i] = -1.f;
+    for (int i = 0; i < 16; ++i) ms[i] = -1.f;
 #ifndef SURTR_EMUL
     (void)hipSetDevice(ctx->device);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 16; ++i)
         if (ctx->ev_valid[i]) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ms[i] = t; }
 #endif
     return SURTR_OK;

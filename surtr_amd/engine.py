@@ -131,9 +131,9 @@ class Engine:
         self._ck(lib().surtr_set_profiling(self._h, ctypes.c_int(int(on))))
 
     def kernel_times(self):
-        ms = (ctypes.c_float * 8)()
+        ms = (ctypes.c_float * 16)()
         self._ck(lib().surtr_kernel_times(self._h, ms))
-        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex")
+        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
     def upload_pieces(self, meshes, convexes):
