@@ -94,7 +94,7 @@ int surtr_set_arena(surtr_ctx* ctx, uint64_t verts, uint64_t nbrs, uint64_t idx)
 /* Per-kernel timing with HIP events recorded on the work stream (the reference's TIMER_* phase
  * timers, Inc/pch.h:122-141, Src/Surtr.cpp:1917-1941).  ms[i] = duration of the last launch of
  * 0 clip_pairs (Mesh), 1 frag_table, 2 refit, 3 faces, 4 out_scan, 5 pack, 6 clip_convex, 7 prep_pairs,
- * 8 clip_pairs_big (runs beside clip_pairs on an internal stream); -1 where not run. */
+ * 8 clip_pairs_big (clip_pairs runs beside it on an internal stream); -1 where not run. */
 int surtr_set_profiling(surtr_ctx* ctx, int on);
 int surtr_kernel_times(surtr_ctx* ctx, float ms[16]);
 
