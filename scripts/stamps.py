@@ -29,3 +29,8 @@ print("per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[16] / max(buf[1
 print("big kernel: pair cost histogram:", [buf[51 + i] for i in range(10)])
 print("big kernel: per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[48] / max(buf[50], 1), buf[49], buf[50]))
 eng.close()
+
+if flags & 2:
+    print("k_faces: successors %d, pointer jumping %d, owners+loops %d, wave ears %d, lane ears %d, compaction %d; faces > 64 vertices: %d (avg %.1f)" % (buf[60], buf[61], buf[62], buf[63], buf[64], buf[65], buf[66], buf[67] / max(buf[66], 1)))
+    print("k_faces: fragment cost histogram (cycles < 2^15, 2^16, ...):", [buf[70 + i] for i in range(10)], "max", buf[68], "largest slow fragment n", buf[69])
+    print("k_faces: slowest fragment: n %d H %d faces %d | succ %d jump %d own %d wave %d lane %d compact %d" % (buf[69], buf[77], buf[78], buf[32], buf[33], buf[34], buf[35], buf[36], buf[37]))

@@ -53,7 +53,7 @@
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
 __device__ unsigned long long g_stamp[80];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
-#define STAMP(i) do { if (threadIdx.x == 0 && blockDim.x > 64) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); sh.ph[i] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0 && blockDim.x > 64) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); sh.ph[(i) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
 #define COUNT(i) do { if (threadIdx.x == 0 && blockDim.x > 64) atomicAdd(&g_stamp[i], 1ull); } while (0)
 #else
 #define COUNT(i) do { } while (0)

@@ -905,8 +905,8 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         __syncthreads();
         if (err == 0 && tid == 0)
         {
-            fr.cv_off = nvoff; fr.cv_n = ncn; fr.ch_off = nhoff; fr.ch_n = nchn;
-            frags[f] = fr;
+            // field-wise: k_faces updates other fields of the same record at the same time
+            frags[f].cv_off = nvoff; frags[f].cv_n = ncn; frags[f].ch_off = nhoff; frags[f].ch_n = nchn;
         }
         if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
     }
@@ -1092,6 +1092,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                                                     Arena A)
 {
     __shared__ Shared sh;
+    // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
+    constexpr uint32_t FL_V = 1024, FL_H = 4096;
+    __shared__ uint16_t f_loff[FL_V]; __shared__ uint16_t f_llen[FL_V]; __shared__ uint16_t f_nbr[FL_H]; __shared__ uint8_t f_vis[FL_H];
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
     int32_t* base = FS.base + (size_t)blockIdx.x * FS.per_wg;
@@ -1110,6 +1113,11 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         if (f >= nf) break;
         FragRec fr = frags[f];
         const uint32_t n = fr.mv_n, H = fr.mh_n;
+        STAMP_DECL;
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long frag_t0 = __builtin_readcyclecounter();
+        if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
+#endif
         if (H > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY); continue; }
         const float* pos = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t* loff = A.loff + fr.mv_off; const uint32_t* llen = A.llen + fr.mv_off;
@@ -1139,6 +1147,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             if (dup) sh.flagBad = 1;
         }
         __syncthreads();
+        STAMP(60);
         const bool irregular = sh.flagBad != 0;
         uint32_t nfaces = 0, lensum = 0;
         int32_t* faceLo = nxB; int32_t* faceLen = keyB;
@@ -1159,6 +1168,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 int32_t* t1 = kc; kc = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
             }
             faceLo = xn; faceLen = kn;
+            STAMP(61);
             // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order, Src/Poly.cpp:94-122)
             auto vertex_of = [&](uint32_t e) -> uint32_t {
                 uint32_t lo_v = 0, hi_v = n;
@@ -1208,35 +1218,40 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         else
         {
             // literal ExtractFaces (Src/Poly.cpp:89-126) on one lane; the visited set is keyed by the
-            // (vertex, neighbour) pair = the first slot holding that neighbour
-            if (tid == 0)
+            // (vertex, neighbour) pair = the first slot holding that neighbour.  Such fragments are small: their
+            // topology is staged in LDS first, so the lane chases LDS instead of HBM latencies.
+            const bool staged = n <= FL_V && H <= FL_H;
+            if (staged)
             {
-                int32_t* visited = keyA;
-                for (uint32_t e = 0; e < H; ++e) visited[e] = 0;
-                auto slot_of = [&](int32_t a, int32_t b) -> uint32_t {
-                    const uint32_t la = loff[a] - fr.mh_off, na = llen[a];
+                for (uint32_t v = tid; v < n; v += group_size()) { f_loff[v] = (uint16_t)(loff[v] - fr.mh_off); f_llen[v] = (uint16_t)llen[v]; }
+                for (uint32_t e = tid; e < H; e += group_size()) { f_nbr[e] = (uint16_t)nbr[e]; f_vis[e] = 0; }
+            }
+            else for (uint32_t e = tid; e < H; e += group_size()) keyA[e] = 0;
+            __syncthreads();
+            auto extract = [&](auto LO, auto LN, auto* NB, auto* visited) {
+                auto slot_of = [&](uint32_t a, uint32_t b) -> uint32_t {
+                    const uint32_t la = LO(a), na = LN(a);
                     uint32_t q = 0;
-                    while (q < na && nbr[la + q] != b) ++q;
+                    while (q < na && (uint32_t)NB[la + q] != b) ++q;
                     return la + (q < na ? q : 0u);
                 };
                 uint32_t nfc = 0, lo = 0; bool bad = false;
                 for (uint32_t i = 0; i < n && !bad; ++i)
                 {
-                    const uint32_t li = loff[i] - fr.mh_off, ni = llen[i];
+                    const uint32_t li = LO(i), ni = LN(i);
                     for (uint32_t s = 0; s < ni && !bad; ++s)
                     {
-                        const int32_t adj = nbr[li + s];
-                        if (visited[slot_of((int32_t)i, adj)]) continue;
+                        const uint32_t adj = NB[li + s];
+                        if (visited[slot_of(i, adj)]) continue;
                         if (lo + 1 > HF || nfc >= HF) { bad = true; break; }
                         uint32_t len = 1; loopbuf[lo] = (int32_t)i;
-                        int32_t prev = (int32_t)i, curv = adj;
-                        while (curv != (int32_t)i)
+                        uint32_t prev = i, curv = adj;
+                        while (curv != i)
                         {
                             visited[slot_of(prev, curv)] = 1;
                             if (lo + len >= HF || len > H) { bad = true; break; }
-                            loopbuf[lo + len++] = curv;
-                            const uint32_t lc = loff[curv] - fr.mh_off;
-                            const int32_t nx = face_next(nbr + lc, llen[curv], prev);
+                            loopbuf[lo + len++] = (int32_t)curv;
+                            const uint32_t nx = face_next(NB + LO(curv), LN(curv), prev);
                             prev = curv; curv = nx;
                         }
                         if (bad) break;
@@ -1245,6 +1260,11 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                     }
                 }
                 sh.misc[0] = nfc; sh.misc[1] = lo; sh.misc[2] = bad ? 1u : 0u;
+            };
+            if (tid == 0)
+            {
+                if (staged) extract([&](uint32_t v) { return (uint32_t)f_loff[v]; }, [&](uint32_t v) { return (uint32_t)f_llen[v]; }, f_nbr, f_vis);
+                else extract([&](uint32_t v) { return loff[v] - fr.mh_off; }, [&](uint32_t v) { return llen[v]; }, nbr, keyA);
             }
             __syncthreads();
             nfaces = sh.misc[0]; lensum = sh.misc[1];
@@ -1253,6 +1273,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
         }
         __syncthreads();
+        STAMP(62);
         // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
         //    room for 3*len indices at 3*lo
 #ifndef SURTR_EMUL
@@ -1263,6 +1284,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             const uint32_t cnt = ear_clip_face_wave(pos, loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
             if (lane_id() == 0) fcnt[fi] = cnt;
         }
+        __syncthreads();
+        STAMP(63);
 #endif
         for (uint32_t fi = tid; fi < nfaces; fi += group_size())
         {
@@ -1272,8 +1295,12 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
 #endif
             uint32_t* out = tri + 3u * (size_t)lo;
             fcnt[fi] = (len >= 3u) ? ear_clip_face(pos, loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out) : 0u;
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+            if (len > 64u) { atomicAdd(&g_stamp[66], 1ull); atomicAdd(&g_stamp[67], (unsigned long long)len); }
+#endif
         }
         __syncthreads();
+        STAMP(64);
         // 5. compact the triangle lists of the faces, in face order, into the index arena
         auto cntfn = [&](uint32_t fi) -> uint2 { return make_uint2(fcnt[fi], 0u); };
         uint32_t nidx = 0, dum = 0;
@@ -1298,7 +1325,11 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 }
             }
         }
-        if (tid == 0) { fr.idx_off = ioff; fr.idx_n = nidx; frags[f] = fr; }
+        if (tid == 0) { frags[f].idx_off = ioff; frags[f].idx_n = nidx; }     // field-wise: k_refit runs beside this kernel
+        STAMP(65);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - frag_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 14 ? 0 : bkt - 14; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[70 + bkt], 1ull); const unsigned long long old = atomicMax(&g_stamp[68], d); if (d > old) { g_stamp[69] = n; g_stamp[61 + 16] = H; g_stamp[62 + 16] = nfaces; for (int q = 0; q < 6; ++q) g_stamp[32 + q] = sh.ph[(60 + q) & 15]; } }
+#endif
     }
 }
 
@@ -2077,11 +2108,22 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
                        ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list);
     PROF_END(1);
+    // refit (Convex) and faces (Mesh) of the fragments are independent: side by side on the two streams
+    const bool both = (flags & SURTR_EVT_REFIT) && (flags & SURTR_EVT_RENDER);
+    hipStream_t st_refit = st;
+#ifndef SURTR_EMUL
+    if (both)
+    {
+        HIPCHK(hipEventRecord(ctx->ev_prep, st));
+        HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
+        st_refit = st2;
+    }
+#endif
     if (flags & SURTR_EVT_REFIT)
     {
-        PROF_BEGIN(2);
-        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
-        PROF_END(2);
+        PROF_BEGIN_ON(2, st_refit);
+        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
+        PROF_END_ON(2, st_refit);
     }
     if (flags & SURTR_EVT_RENDER)
     {
@@ -2090,6 +2132,13 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->blk_per_wg, ctx->arena);
         PROF_END(3);
     }
+#ifndef SURTR_EMUL
+    if (both)
+    {
+        HIPCHK(hipEventRecord(ctx->ev_big, st2));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
+    }
+#endif
     PROF_BEGIN(4);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     PROF_END(4);
