@@ -52,9 +52,14 @@
 // global table that no product code reads.
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
 __device__ unsigned long long g_stamp[80];
+#ifdef SURTR_STAMP_SMALL
+#define STAMP_WHO (blockDim.x == 64 && gridDim.x > 1900)
+#else
+#define STAMP_WHO (blockDim.x > 64)
+#endif
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
-#define STAMP(i) do { if (threadIdx.x == 0 && blockDim.x > 64) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); sh.ph[(i) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
-#define COUNT(i) do { if (threadIdx.x == 0 && blockDim.x > 64) atomicAdd(&g_stamp[i], 1ull); } while (0)
+#define STAMP(i) do { if (threadIdx.x == 0 && STAMP_WHO) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); sh.ph[(i) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
+#define COUNT(i) do { if (threadIdx.x == 0 && STAMP_WHO) atomicAdd(&g_stamp[i], 1ull); } while (0)
 #else
 #define COUNT(i) do { } while (0)
 #define STAMP_DECL
@@ -68,6 +73,13 @@ __device__ unsigned long long g_stamp[80];
 #define SURTR_UNIFORM(x) (x)
 #else
 #define SURTR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#endif
+#ifndef SURTR_KEEPALL_V
+#ifdef SURTR_EMUL
+#define SURTR_KEEPALL_V 12u     // (emulation: small, so that the tests still run the culling on small meshes)
+#else
+#define SURTR_KEEPALL_V 256u    // solids up to this many vertices skip the pre-pass culling
+#endif
 #endif
 #define SURTR_NEVER 0xFFu       // fc of a vertex no plane clips
 #define SURTR_WALK0 12u        // walk steps before the cap-run shortcut is built
@@ -433,6 +445,19 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
     // needy: work list of vertices that need the exact neighbour test: v | fc << 24
 
+    // A solid of a few hundred vertices (a Convex, a refit box) is kept whole: the plane loop only touches what a
+    // plane clips anyway, and the tests below would cost more than they save.
+    const bool keepall = V <= SURTR_KEEPALL_V;
+    if (keepall)
+    {
+        for (uint32_t b = tid; b < nbV; b += group_size())
+        {
+            const uint32_t left = V - (b << SURTR_LSH);
+            bmask[b] = left >= SURTR_LANES ? ~0ull : ((1ull << left) - 1ull);
+        }
+    }
+    if (!keepall)
+    {
     // ---- A1: stream all vertices: first cutting plane + conservative ball test, no neighbour is read ----
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
@@ -637,6 +662,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
         (void)zero;
         wave_hist_add(sh.hist, f, drop);
     }
+    }   // !keepall
     __syncthreads();
     STAMP(1);
     // ---- A3: per 64-block (kept vertices, their ring entries) ----

@@ -169,8 +169,21 @@ typedef LdsTopoT<2 * SURTR_LV, 2 * SURTR_LH> LdsTopoBig;   // the few Mesh solid
 #ifdef SURTR_EMUL
 typedef LdsTopoT<64, 512> LdsTopoSmall;                 // (emulation: small enough to exercise the fallback too)
 #else
-typedef LdsTopoT<512, 4096> LdsTopoSmall;               // Convex solids: one wave per task, many tasks per CU
+typedef LdsTopoT<256, 2048> LdsTopoSmall;               // Convex solids: one wave per task, many tasks per CU
 #endif
+
+// Work arrays of a Topo in LDS.  Convex solids have a few dozen vertices: with positions and work lists next to the
+// topology no phase of their plane loop waits for HBM.  Used when the input solid has at most N vertices.
+template <uint32_t N>
+struct LdsWorkT
+{
+    static constexpr uint32_t kN = N;
+    float pos[3 * N];
+    uint32_t succ[N], pred[N], pcnt[N], aux0[N], aux1[N], aux2[N], aux3[N];
+    int8_t gcomp[N];
+};
+typedef LdsWorkT<LdsTopoSmall::kLV> LdsWorkSmall;
+struct NoLdsWork { static constexpr uint32_t kN = 0; };
 
 template <class LT>
 __device__ static Topo<InLds> lds_topo(Scratch& S, LT& L)
@@ -180,6 +193,22 @@ __device__ static Topo<InLds> lds_topo(Scratch& S, LT& L)
     T.succ = S.g_succ; T.pred = S.g_pred; T.pcnt = S.g_pcnt; T.aux0 = S.aux0; T.aux1 = S.aux1; T.aux2 = S.aux2; T.aux3 = S.aux3; T.blk = L.blk;
     T.capV = LT::kLV < S.CV ? LT::kLV : S.CV; T.capH = LT::kLH;
     T.nS = T.nLive = T.hUsed = 0; T.kcur = T.n0cur = 0; T.zmode = false;
+    return T;
+}
+// the same with the work arrays in LDS (W) when the input is small enough for them
+template <class LT, class LW>
+__device__ static Topo<InLds> lds_topo(Scratch& S, LT& L, LW* W, uint32_t nv_in)
+{
+    Topo<InLds> T = lds_topo(S, L);
+    if constexpr (LW::kN != 0)
+    {
+        if (W != nullptr && nv_in <= LW::kN)
+        {
+            T.pos = W->pos; T.succ = W->succ; T.pred = W->pred; T.pcnt = W->pcnt;
+            T.aux0 = W->aux0; T.aux1 = W->aux1; T.aux2 = W->aux2; T.aux3 = W->aux3; T.gcomp = W->gcomp;
+            if (T.capV > LW::kN) T.capV = LW::kN;
+        }
+    }
     return T;
 }
 
@@ -203,13 +232,13 @@ __device__ static int clip_global(const SolidIn in, uint32_t F, Scratch& S, Shar
 
 // Clips `in` by sh.planes[0..F) and hands the resulting Topo (nLive == 0: empty) to `consume`.
 // Returns 0 or an error code (uniform over the workgroup).
-template <class LT, class Consume>
-__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume)
+template <class LT, class Consume, class LW = NoLdsWork>
+__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume, LW* W = nullptr)
 {
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
     int rc;
     {
-        Topo<InLds> T = lds_topo(S, L);
+        Topo<InLds> T = lds_topo(S, L, W, in.nv);
         // pre-pass masks sit in the tail of the ring area while the reduced solid is being emitted
         // (the tail is free again afterwards); a copy of the bit mask goes to global scratch for the
         // all-in-plane corner case of clip_planes
@@ -460,7 +489,10 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
 
 // ------------------------------------------------------------- k_clip_convex
 // Convex of every (cell, piece) pair first (Src/Surtr.cpp:1466-1468): small solids, one wave per task.
-__global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const float4* __restrict__ planes,
+#ifndef SURTR_SMALL_WAVES
+#define SURTR_SMALL_WAVES 2
+#endif
+__global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SURTR_SMALL_WAVES, 8))) void k_clip_convex(Pieces P, const float4* __restrict__ planes,
                                                     const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                     uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                     ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
@@ -468,6 +500,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const flo
 {
     __shared__ Shared sh;
     __shared__ LdsTopoSmall L;
+    __shared__ LdsWorkSmall W;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     while (true)
@@ -495,7 +528,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_clip_convex(Pieces P, const flo
             err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
                 if (T.nLive == 0) return 0;
                 return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
-            });
+            }, &W);
             __syncthreads();
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
@@ -798,6 +831,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
     __shared__ ArgD slotD[SURTR_NWAVE];
     __shared__ float nrm[4][3];
     __shared__ LdsTopoSmall L;
+    __shared__ LdsWorkSmall W;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
@@ -901,7 +935,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         int err = clip_any(cin, 8, S, sh, L, [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
-        });
+        }, &W);
         __syncthreads();
         if (err == 0 && tid == 0)
         {
@@ -1605,7 +1639,9 @@ int surtr_create(int device, surtr_ctx** out)
             if (const char* e = getenv("SURTR_WG_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = (uint32_t)v; }
             ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
             ctx->max_wg_faces = (uint32_t)prop.multiProcessorCount * 4u;
-            ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * 8u;
+            uint32_t small_per_cu = 8u;
+            if (const char* e = getenv("SURTR_SMALL_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) small_per_cu = (uint32_t)v; }
+            ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * small_per_cu;
             uint32_t prep_per_cu = 6u;
             if (const char* e = getenv("SURTR_PREP_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) prep_per_cu = (uint32_t)v; }
             ctx->max_wg_prep = (uint32_t)prop.multiProcessorCount * prep_per_cu;
