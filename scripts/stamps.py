@@ -32,6 +32,8 @@ print("big kernel: pair cost histogram:", [buf[51 + i] for i in range(10)])
 print("big kernel: per-WG busy: avg %.3g max %.3g cycles over %d WGs" % (buf[48] / max(buf[50], 1), buf[49], buf[50]))
 eng.close()
 
+print("prep kernel: pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[62 + i] for i in range(8)])
+print("prep kernel: per-WG lifetime avg %.3g max %.3g, work avg %.3g max %.3g cycles over %d WGs" % (buf[56] / max(buf[58], 1), buf[57], buf[59] / max(buf[58], 1), buf[60], buf[58]))
 if flags & 2:
     print("k_faces: successors %d, pointer jumping %d, owners+loops %d, wave ears %d, lane ears %d, compaction %d; faces > 64 vertices: %d (avg %.1f)" % (buf[60], buf[61], buf[62], buf[63], buf[64], buf[65], buf[66], buf[67] / max(buf[66], 1)))
     print("k_faces: fragment cost histogram (cycles < 2^15, 2^16, ...):", [buf[70 + i] for i in range(10)], "max", buf[68], "largest slow fragment n", buf[69])

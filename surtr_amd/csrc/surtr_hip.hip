@@ -570,6 +570,10 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 4);
     unsigned long long* gmask = (unsigned long long*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+    const unsigned long long wg_t0 = __builtin_readcyclecounter();
+    unsigned long long wg_work = 0;
+#endif
     while (true)
     {
         __syncthreads();
@@ -582,6 +586,9 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
         if (V < SURTR_PREP_MINV || V > pool.VMAX) { if (tid == 0) enqueue(p, V > pool.VMAX ? 13u : 0u); continue; }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long pair_t0 = __builtin_readcyclecounter();
+#endif
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
         __syncthreads();
@@ -637,7 +644,13 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                 cls = (n + capV / 5u > capV || hsum + SURTR_LH / 6u > SURTR_LH) ? 14u : 1u + (n >> 9 < 12u ? n >> 9 : 12u);
             if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; wg_work += d; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 7) bkt = 7; atomicAdd(&g_stamp[62 + bkt], 1ull); }
+#endif
     }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp[56], d); atomicMax(&g_stamp[57], d); atomicAdd(&g_stamp[58], 1ull); atomicAdd(&g_stamp[59], wg_work); atomicMax(&g_stamp[60], wg_work); }
+#endif
 }
 
 // -------------------------------------------------------------- k_clip_pairs
