@@ -1142,6 +1142,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
     // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
     constexpr uint32_t FL_V = 1024, FL_H = 4096;
     __shared__ uint16_t f_loff[FL_V]; __shared__ uint16_t f_llen[FL_V]; __shared__ uint16_t f_nbr[FL_H]; __shared__ uint8_t f_vis[FL_H];
+    __shared__ uint32_t f_cov[FL_H];
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
     int32_t* base = FS.base + (size_t)blockIdx.x * FS.per_wg;
@@ -1198,10 +1199,88 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         const bool irregular = sh.flagBad != 0;
         uint32_t nfaces = 0, lensum = 0;
         int32_t* faceLo = nxB; int32_t* faceLen = keyB;
-        if (!irregular)
+        bool serial_extract = false;
+        int32_t* kc = keyA;           // per half-edge: the smallest half-edge whose face walk visits it (== itself: a face starts here)
+        const bool staged = irregular && n <= FL_V && H <= FL_H;
+        if (irregular)
+        {
+            // Sliver fragment (a ring lists a neighbour twice): the reference keys its visited set by the (vertex, neighbour)
+            // pair = the first slot holding that neighbour, and walks by first occurrence (FaceLoop).  Such fragments are
+            // small: work on an LDS copy.  Face starts are found speculatively -- every pair walks its face and leaves its
+            // id (atomicMin) on the pairs it visits; starts = pairs that kept their own id -- and then checked against the
+            // sequential definition (a pair starts a face iff no earlier start's walk visits it) by walking from the starts
+            // only.  A failed check falls back to the literal serial loop.
+            if (!staged) serial_extract = true;
+            else
+            {
+                for (uint32_t v = tid; v < n; v += group_size()) { f_loff[v] = (uint16_t)(loff[v] - fr.mh_off); f_llen[v] = (uint16_t)llen[v]; }
+                for (uint32_t e = tid; e < H; e += group_size()) { f_nbr[e] = (uint16_t)nbr[e]; f_vis[e] = 0; f_cov[e] = 0xFFFFu; }
+                __syncthreads();
+                auto slot_of = [&](uint32_t a, uint32_t b) -> uint32_t {
+                    const uint32_t la = f_loff[a], na = f_llen[a];
+                    uint32_t q = 0;
+                    while (q < na && (uint32_t)f_nbr[la + q] != b) ++q;
+                    return la + (q < na ? q : 0u);
+                };
+                auto walk_mark = [&](uint32_t i, uint32_t e) {          // visits of the face that starts with pair e = (i, nbr[e])
+                    uint32_t prev = i, curv = f_nbr[e], steps = 0;
+                    while (curv != i && steps++ <= H)
+                    {
+                        atomicMin(&f_cov[slot_of(prev, curv)], e);
+                        const uint32_t nx = face_next(f_nbr + f_loff[curv], f_llen[curv], prev);
+                        prev = curv; curv = nx;
+                    }
+                    atomicMin(&f_cov[slot_of(prev, curv)], e);
+                    return steps;
+                };
+                bool toolong = false;
+                for (uint32_t v = tid; v < n; v += group_size())
+                {
+                    const uint32_t lo = f_loff[v], len = f_llen[v];
+                    for (uint32_t sI = 0; sI < len; ++sI)
+                        if (slot_of(v, f_nbr[lo + sI]) == lo + sI && walk_mark(v, lo + sI) > H) toolong = true;
+                }
+                if (toolong) sh.flagBad = 2;
+                __syncthreads();
+                // starts by the speculative pass; then the check pass from those only
+                for (uint32_t v = tid; v < n; v += group_size())
+                {
+                    const uint32_t lo = f_loff[v], len = f_llen[v];
+                    for (uint32_t sI = 0; sI < len; ++sI) { const uint32_t e = lo + sI; f_vis[e] = (f_cov[e] == e) ? 1 : 0; }
+                }
+                __syncthreads();
+                for (uint32_t e = tid; e < H; e += group_size()) f_cov[e] = 0xFFFFu;
+                __syncthreads();
+                for (uint32_t v = tid; v < n; v += group_size())
+                {
+                    const uint32_t lo = f_loff[v], len = f_llen[v];
+                    for (uint32_t sI = 0; sI < len; ++sI) if (f_vis[lo + sI]) walk_mark(v, lo + sI);
+                }
+                __syncthreads();
+                bool mism = false;
+                for (uint32_t v = tid; v < n; v += group_size())
+                {
+                    const uint32_t lo = f_loff[v], len = f_llen[v];
+                    for (uint32_t sI = 0; sI < len; ++sI)
+                    {
+                        const uint32_t e = lo + sI;
+                        const bool canon = slot_of(v, f_nbr[e]) == e;
+                        const uint32_t c = f_cov[e];
+                        if (canon && (c > e || (c == e) != (f_vis[e] != 0))) mism = true;
+                        keyA[e] = (canon && f_vis[e]) ? (int32_t)e : -1;
+                    }
+                }
+                if (mism) sh.flagBad = 2;
+                __syncthreads();
+                if (sh.flagBad == 2) serial_extract = true;
+                __syncthreads();
+                faceLo = nxB; faceLen = keyB;
+            }
+        }
+        else
         {
             // 2. minimum half-edge id of every loop by pointer jumping
-            int32_t* kc = keyA; int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
+            int32_t* kn = keyB; int32_t* xc = nxA; int32_t* xn = nxB;
             for (uint32_t span = 1; span < H; span <<= 1)
             {
                 for (uint32_t e = tid; e < H; e += group_size())
@@ -1216,6 +1295,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             }
             faceLo = xn; faceLen = kn;
             STAMP(61);
+        }
+        if (!serial_extract)
+        {
             // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order, Src/Poly.cpp:94-122)
             auto vertex_of = [&](uint32_t e) -> uint32_t {
                 uint32_t lo_v = 0, hi_v = n;
@@ -1265,14 +1347,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         else
         {
             // literal ExtractFaces (Src/Poly.cpp:89-126) on one lane; the visited set is keyed by the
-            // (vertex, neighbour) pair = the first slot holding that neighbour.  Such fragments are small: their
-            // topology is staged in LDS first, so the lane chases LDS instead of HBM latencies.
-            const bool staged = n <= FL_V && H <= FL_H;
-            if (staged)
-            {
-                for (uint32_t v = tid; v < n; v += group_size()) { f_loff[v] = (uint16_t)(loff[v] - fr.mh_off); f_llen[v] = (uint16_t)llen[v]; }
-                for (uint32_t e = tid; e < H; e += group_size()) { f_nbr[e] = (uint16_t)nbr[e]; f_vis[e] = 0; }
-            }
+            // (vertex, neighbour) pair = the first slot holding that neighbour
+            if (staged) { for (uint32_t e = tid; e < H; e += group_size()) f_vis[e] = 0; }
             else for (uint32_t e = tid; e < H; e += group_size()) keyA[e] = 0;
             __syncthreads();
             auto extract = [&](auto LO, auto LN, auto* NB, auto* visited) {
