@@ -16,7 +16,7 @@ buf = (ctypes.c_ulonglong * 80)()
 L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
-names = ["pre: A1 stream", "pre: A2 exact", "pre: A3+emit", "pre: hist", "plane: classify", "plane: cut links patch", "plane: relink finalize/serial", "plane: tombstones",
+names = ["pre: A1 stream", "pre: A2 exact", "pre: emit", "pre: A3 block counts + scan", "plane: classify", "plane: cut links patch", "plane: relink finalize/serial", "plane: tombstones",
          "plane: cut scan", "plane: cut sparse sweep", "plane: cut dense create", "plane: chain jump", "plane: walks (first 12 steps)", "plane: pred check", "plane: resumed walks"]
 tot = sum(buf[i] for i in range(15))
 for i, n in enumerate(names):
@@ -34,6 +34,7 @@ eng.close()
 
 print("prep kernel: pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[62 + i] for i in range(8)])
 print("prep kernel: per-WG lifetime avg %.3g max %.3g, work avg %.3g max %.3g cycles over %d WGs" % (buf[56] / max(buf[58], 1), buf[57], buf[59] / max(buf[58], 1), buf[60], buf[58]))
+print("prep kernel (lane-0 cycles): planes %d, select %d, image alloc %d, mask copy %d, emit %d, hist+header %d" % tuple(buf[70:76]))
 if flags & 2:
     print("k_faces: successors %d, pointer jumping %d, owners+loops %d, wave ears %d, lane ears %d, compaction %d; faces > 64 vertices: %d (avg %.1f)" % (buf[60], buf[61], buf[62], buf[63], buf[64], buf[65], buf[66], buf[67] / max(buf[66], 1)))
     print("k_faces: fragment cost histogram (cycles < 2^15, 2^16, ...):", [buf[70 + i] for i in range(10)], "max", buf[68], "largest slow fragment n", buf[69])

@@ -447,14 +447,23 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
 
     // A solid of a few hundred vertices (a Convex, a refit box) is kept whole: the plane loop only touches what a
     // plane clips anyway, and the tests below would cost more than they save.
+    // bblk[b].y collects the ring entries of the kept vertices of block b wherever a vertex is found to be kept (its
+    // degree is at hand or one more load in flight there), so that the block table needs no pass over the vertices
     const bool keepall = V <= SURTR_KEEPALL_V;
+    for (uint32_t b = tid; b < nbV; b += group_size()) bblk[b] = make_uint2(0u, 0u);
+    __syncthreads();
+    auto keep_deg = [&](uint32_t v, uint32_t deg) {
+        atomicAdd(&bblk[v >> SURTR_LSH].y, deg);
+        if (deg > InLds::MAXLEN / 2u) sh.flagBad = 1;
+    };
     if (keepall)
     {
         for (uint32_t b = tid; b < nbV; b += group_size())
         {
             const uint32_t left = V - (b << SURTR_LSH);
-            bmask[b] = left >= SURTR_LANES ? ~0ull : ((1ull << left) - 1ull);
+            bmask[b] = left >= SURTR_LANES ? (~0ull >> (64u - SURTR_LANES)) : ((1ull << left) - 1ull);
         }
+        for (uint32_t v = tid; v < V; v += group_size()) keep_deg(v, in.llen[v]);
     }
     if (!keepall)
     {
@@ -581,6 +590,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
                 }
             }
             else if (l == 0) bmask[wb] = mk;
+            if (keep) keep_deg(v, in.llen[v]);
             if (mn)
             {
                 uint32_t base = 0;
@@ -650,6 +660,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
 #else
                 atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
 #endif
+                keep_deg(v, deg);
             }
             else
             {
@@ -665,29 +676,13 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     }   // !keepall
     __syncthreads();
     STAMP(1);
-    // ---- A3: per 64-block (kept vertices, their ring entries) ----
-    {
-        bool toolong = false;
-        for (uint32_t b = w; b < nbV; b += group_waves())
-        {
-            const unsigned long long m = bmask[b];
-            uint2 inc = make_uint2(0u, 0u);
-            if (m != 0ull)
-            {
-                const uint32_t v = (b << SURTR_LSH) + l;
-                const bool keep = (m >> l) & 1ull;
-                const uint32_t deg = keep ? in.llen[v] : 0u;
-                if (deg > InLds::MAXLEN / 2u) toolong = true;
-                inc = wave_incl_scan2(make_uint2(keep ? 1u : 0u, deg));
-            }
-            if (l == SURTR_LANES - 1u) bblk[b] = inc;
-        }
-        if (toolong) sh.flagBad = 1;
-    }
+    // ---- A3: per 64-block (kept vertices, their ring entries): the counts come from the mask, the entries were summed above ----
+    for (uint32_t b = tid; b < nbV; b += group_size()) bblk[b].x = (uint32_t)__builtin_popcountll(bmask[b]);
     __syncthreads();
     uint32_t n = 0, hsum = 0;
     scan_block_array(nbV, bblk, sh, n, hsum);
     __syncthreads();
+    STAMP(3);
     n_out = n; hsum_out = hsum;
 }
 

@@ -589,11 +589,13 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
+        STAMP_DECL;
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
         __syncthreads();
         SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, V, P.mtri + m0, P.mrad + m0,
                     P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+        STAMP(70);
         const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
         unsigned long long* bmask = nbV <= SURTR_PREP_NB ? lmask : gmask;
         uint2* bblk = nbV <= SURTR_PREP_NB ? lblk : gblk;
@@ -605,6 +607,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
         __syncthreads();
+        STAMP(71);
         uint32_t fmt = IMG_NARROW, off16 = 0;
         if (n == 0) fmt = IMG_EMPTY;
         else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
@@ -618,20 +621,24 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             __syncthreads();
             if ((uint64_t)off16 + need16 > IA.cap16) fmt = IMG_NONE;      // arena full: k_clip_pairs does this pair alone
         }
+        STAMP(72);
         if (fmt == IMG_NARROW)
         {
             char* img = IA.base + (size_t)off16 * 16u;
             unsigned long long* gm = (unsigned long long*)(img + lay.mask);
             for (uint32_t b = tid; b < nbV; b += group_size()) gm[b] = bmask[b];
+            STAMP(73);
             Topo<InLds> T;
             T.loff = (uint16_t*)(img + lay.loff); T.llen = (uint8_t*)(img + lay.llen); T.fc = (uint8_t*)(img + lay.comp); T.gcomp = nullptr;
             T.ring = (uint16_t*)(img + lay.ring); T.pos = (float*)(img + lay.pos);
             T.succ = T.pred = T.pcnt = T.aux0 = T.aux1 = T.aux2 = T.aux3 = nullptr; T.blk = nullptr;
             T.capV = n; T.capH = hsum; T.nS = T.nLive = T.hUsed = 0; T.kcur = T.n0cur = 0; T.zmode = false;
             prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);      // also counts sh.nzero
+            STAMP(74);
             prepass_finish_hist(F, sh);
             uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* nz = (uint32_t*)(img + lay.nzero);
             for (uint32_t k = tid; k < F; k += group_size()) { hs[k] = sh.hist[k]; zs[k] = sh.zhist[k]; nz[k] = sh.nzero[k]; }
+            STAMP(75);
         }
         if (tid == 0)
         {
