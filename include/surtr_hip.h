@@ -185,6 +185,21 @@ int surtr_hull_normals(uint32_t n, const float* points, uint32_t limit, uint32_t
 int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const float* normals, double max_axis_scale,
                           float plane_gap_inv, float* planes);
 
+/* Poly::Moments (Src/Poly.cpp:55-87): signed volume and centroid of a closed solid (host; the test invariant of
+ * fragment volumes partition the input). */
+int surtr_moments(uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, double* volume, float centroid[3]);
+
+/* ---- mesh files either side of the path (host) --------------------------------- */
+/* Wavefront OBJ in, with the conventions of Surtr::LoadModelData and its assimp flags (Src/Surtr.cpp:2683-2727):
+ * one vertex per distinct position in order of first use, polygons as fans, winding flipped, x negated, then
+ * scale/translate.  Count-then-fill: with pos or tris NULL only *n_verts / *n_tris are written. */
+int surtr_read_obj(const char* path, const float scale[3], const float translate[3], uint32_t cap_verts, uint32_t cap_tris,
+                   float* pos, int32_t* tris, uint32_t* n_verts, uint32_t* n_tris);
+/* The render buffers of an event (surtr_fragments: vnc = 36-byte VertexNormalColor, Inc/Mesh.h:4-13) as one OBJ
+ * object per fragment. */
+int surtr_write_obj(const char* path, uint32_t n_frag, const int32_t* frag_ids, const uint32_t* mesh_vert_off, const float* vnc,
+                    const uint32_t* idx_off, const uint32_t* idx);
+
 /* ---- the step after the event: compound regrouping (host side) ---------------- */
 /* Surtr::ConvexOutOfSphere (Src/Surtr.cpp:2415-2458) for one Convex; sphere_points are already placed. */
 int surtr_convex_out_of_sphere(uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, uint32_t n_sphere,

@@ -2,6 +2,10 @@
 // GPU path: mesh ingestion (neighbour rings) and fracture-pattern construction
 // (bounded Voronoi cells).  Both run once per model / pattern, not per event.
 #include <algorithm>
+#include <cstdlib>
+#include <cstdio>
+#include <map>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -497,6 +501,82 @@ int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const flo
             out[0] = nn[0]; out[1] = nn[1]; out[2] = nn[2]; out[3] = -dot(q, nn);
         }
     }
+    return SURTR_OK;
+}
+
+// ---- mesh files either side of the path ----------------------------------------------
+// Surtr::LoadModelData (Src/Surtr.cpp:2683-2727) reads through assimp with Triangulate | FlipWindingOrder |
+// JoinIdenticalVertices, negates x and applies scale/translate.  assimp is not in this image; this reader restates
+// those conventions for Wavefront OBJ (v / f records, negative indices, "i/j/k" corners): one vertex per distinct
+// position in order of first use by a face, polygons as fans, every triangle reversed, x negated.  How assimp
+// triangulates faces of more than four corners is not reproduced (unpinned): feed triangle meshes for exact results.
+int surtr_read_obj(const char* path, const float scale[3], const float translate[3], uint32_t cap_verts, uint32_t cap_tris,
+                   float* pos, int32_t* tris, uint32_t* n_verts, uint32_t* n_tris)
+{
+    if (!path || !scale || !translate || !n_verts || !n_tris) return SURTR_E_INVALID;
+    FILE* f = fopen(path, "r");
+    if (!f) return SURTR_E_INVALID;
+    std::vector<std::array<float, 3>> raw;
+    std::vector<int> corner;                 // raw vertex index per triangle corner
+    char line[4096];
+    while (fgets(line, sizeof line, f))
+    {
+        if (line[0] == 'v' && (line[1] == ' ' || line[1] == '\t'))
+        {
+            float x = 0, y = 0, z = 0;
+            if (sscanf(line + 1, "%f %f %f", &x, &y, &z) == 3) raw.push_back({x, y, z});
+        }
+        else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t'))
+        {
+            std::vector<int> poly;
+            for (char* tok = strtok(line + 1, " \t\r\n"); tok; tok = strtok(nullptr, " \t\r\n"))
+            {
+                const long i = strtol(tok, nullptr, 10);
+                if (i == 0) continue;
+                poly.push_back(i > 0 ? (int)i - 1 : (int)raw.size() + (int)i);
+            }
+            for (size_t k = 1; k + 1 < poly.size(); ++k) { corner.push_back(poly[0]); corner.push_back(poly[k]); corner.push_back(poly[k + 1]); }
+        }
+    }
+    fclose(f);
+    std::map<std::array<float, 3>, int> id;
+    std::vector<int> first;                  // joined vertex -> raw index
+    std::vector<int> out(corner.size());
+    for (size_t c = 0; c < corner.size(); ++c)
+    {
+        if (corner[c] < 0 || corner[c] >= (int)raw.size()) return SURTR_E_INVALID;
+        auto it = id.find(raw[corner[c]]);
+        if (it == id.end()) { it = id.emplace(raw[corner[c]], (int)first.size()).first; first.push_back(corner[c]); }
+        out[c] = it->second;
+    }
+    *n_verts = (uint32_t)first.size(); *n_tris = (uint32_t)(out.size() / 3);
+    if (!pos || !tris) return SURTR_OK;
+    if (cap_verts < *n_verts || cap_tris < *n_tris) return SURTR_E_CAPACITY;
+    for (size_t v = 0; v < first.size(); ++v)
+    {
+        const auto& p = raw[first[v]];
+        pos[3 * v] = -p[0] * scale[0] + translate[0]; pos[3 * v + 1] = p[1] * scale[1] + translate[1]; pos[3 * v + 2] = p[2] * scale[2] + translate[2];
+    }
+    for (size_t t = 0; t < out.size() / 3; ++t) { tris[3 * t] = out[3 * t + 2]; tris[3 * t + 1] = out[3 * t + 1]; tris[3 * t + 2] = out[3 * t]; }
+    return SURTR_OK;
+}
+
+// Fragment writer for the headless harness: the render buffers of an event (36-byte VertexNormalColor + uint32 indices,
+// what DynamicMesh::UpdateMeshData consumes, Inc/Mesh.h:163-207) as one OBJ object per fragment.
+int surtr_write_obj(const char* path, uint32_t n_frag, const int32_t* frag_ids, const uint32_t* mesh_vert_off, const float* vnc,
+                    const uint32_t* idx_off, const uint32_t* idx)
+{
+    if (!path || (n_frag && (!frag_ids || !mesh_vert_off || !vnc || !idx_off || !idx))) return SURTR_E_INVALID;
+    FILE* f = fopen(path, "w");
+    if (!f) return SURTR_E_INVALID;
+    for (uint32_t k = 0; k < n_frag; ++k)
+    {
+        fprintf(f, "o cell%d_piece%d_island%d\n", frag_ids[3 * k], frag_ids[3 * k + 1], frag_ids[3 * k + 2]);
+        for (uint32_t v = mesh_vert_off[k]; v < mesh_vert_off[k + 1]; ++v) fprintf(f, "v %.9g %.9g %.9g\n", vnc[9 * (size_t)v], vnc[9 * (size_t)v + 1], vnc[9 * (size_t)v + 2]);
+        const uint32_t base = mesh_vert_off[k] + 1u;
+        for (uint32_t i = idx_off[k]; i + 2 < idx_off[k + 1]; i += 3) fprintf(f, "f %u %u %u\n", base + idx[i], base + idx[i + 1], base + idx[i + 2]);
+    }
+    fclose(f);
     return SURTR_OK;
 }
 

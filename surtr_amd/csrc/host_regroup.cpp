@@ -93,6 +93,36 @@ struct FaceNode { int cid; double absd; P3 n; std::vector<P3> pts; };
 
 extern "C" {
 
+// Poly::Moments (Src/Poly.cpp:55-87): signed volume and centroid from the fan of every face around vertex 0;
+// per-face terms in float (Vector3 arithmetic), accumulated in double / float exactly as the reference's members are.
+int surtr_moments(uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, double* volume, float centroid[3])
+{
+    if (!volume || !centroid || (nv && (!pos || !nbr_off || !nbr))) return SURTR_E_INVALID;
+    *volume = 0.0; centroid[0] = centroid[1] = centroid[2] = 0.f;
+    if (nv <= 3) return SURTR_OK;
+    const SolidView S{pos, nbr_off, nbr, nv};
+    const P3 origin = S.p(0);
+    double vol = 0.0; P3 c{0.f, 0.f, 0.f};
+    for (const auto& f : faces_of(S))
+    {
+        const size_t n = f.size();
+        const P3 p0 = sub(S.p(f[0]), origin);
+        for (size_t k = 1; k + 1 < n; ++k)
+        {
+            const P3 p1 = sub(S.p(f[k]), origin), p2 = sub(S.p(f[(k + 1) % n]), origin);
+            const float dV = dot(p0, cross(p1, p2));
+            vol += dV;
+            c = P3{c.x + (p0.x + p1.x + p2.x) * dV, c.y + (p0.y + p1.y + p2.y) * dV, c.z + (p0.z + p1.z + p2.z) * dV};
+        }
+    }
+    vol /= 6.0;
+    const double x = 24.0 * vol;
+    const float inv = (float)((x >= 0.0 ? 1.0 : -1.0) / std::max(1.0e-30, std::fabs(x)));     // safeInv (Src/Poly.cpp:33)
+    *volume = vol;
+    centroid[0] = c.x * inv + origin.x; centroid[1] = c.y * inv + origin.y; centroid[2] = c.z * inv + origin.z;
+    return SURTR_OK;
+}
+
 int surtr_convex_out_of_sphere(uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, uint32_t n_sphere,
                                const float* sphere_points, const float origin[3], float radius, int* out)
 {

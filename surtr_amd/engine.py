@@ -393,3 +393,41 @@ def regroup(convexes, piece_cell, n_outside=0, partial=False, sphere_points=None
     if rc:
         raise SurtrError(rc)
     return co[:nc.value + 1].copy(), cp[:co[nc.value]].copy()
+
+
+def moments(solid):
+    """Poly::Moments (Src/Poly.cpp:55-87) of one solid: (volume, centroid)."""
+    pos = np.ascontiguousarray(solid["pos"], np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(solid["off"], np.uint32)
+    nbr = np.ascontiguousarray(solid["nbr"], np.int32)
+    vol = ctypes.c_double(0.0)
+    cen = np.zeros(3, np.float32)
+    rc = lib().surtr_moments(ctypes.c_uint32(pos.shape[0]), _p(pos), _p(off), _p(nbr), ctypes.byref(vol), _p(cen))
+    if rc:
+        raise SurtrError(rc)
+    return float(vol.value), cen
+
+
+def read_obj(path, scale=(1, 1, 1), translate=(0, 0, 0)):
+    """Surtr::LoadModelData conventions (Src/Surtr.cpp:2683-2727) for a Wavefront OBJ: (verts f32[n,3], tris i32[m,3])."""
+    sc = np.asarray(scale, np.float32); tr = np.asarray(translate, np.float32)
+    nv, nt = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = lib().surtr_read_obj(path.encode(), _p(sc), _p(tr), ctypes.c_uint32(0), ctypes.c_uint32(0), None, None, ctypes.byref(nv), ctypes.byref(nt))
+    if rc:
+        raise SurtrError(rc)
+    pos = np.zeros((nv.value, 3), np.float32); tris = np.zeros((nt.value, 3), np.int32)
+    rc = lib().surtr_read_obj(path.encode(), _p(sc), _p(tr), nv, nt, _p(pos), _p(tris), ctypes.byref(nv), ctypes.byref(nt))
+    if rc:
+        raise SurtrError(rc)
+    return pos, tris
+
+
+def write_obj(path, fragments):
+    """One OBJ object per fragment from the render buffers of engine.download()."""
+    fr = fragments
+    ids = np.ascontiguousarray(fr["frag_ids"], np.int32)
+    rc = lib().surtr_write_obj(path.encode(), ctypes.c_uint32(ids.shape[0]), _p(ids), _p(np.ascontiguousarray(fr["mesh_vert_off"], np.uint32)),
+                               _p(np.ascontiguousarray(fr["vnc"], np.float32)), _p(np.ascontiguousarray(fr["idx_off"], np.uint32)),
+                               _p(np.ascontiguousarray(fr["idx"], np.uint32)))
+    if rc:
+        raise SurtrError(rc)

@@ -1,7 +1,8 @@
 // harness.cpp -- headless replacement of the Win32/DX12 shell for the fracture-event path:
 // builds a synthetic closed mesh, a Voronoi pattern, runs ONE fracture event on the GPU and prints a
 // JSON summary (optionally writes the fragments as an OBJ).  Usage:
-//   surtr_harness [--mesh cube|torus] [--cells N] [--nu A --nv B] [--obj out.obj]
+//   surtr_harness [--mesh cube|torus | --obj-in mesh.obj [--scale S]] [--cells N] [--nu A --nv B] [--ach] [--obj out.obj]
+// --ach runs Surtr::PrepareFracture end to end (ACH convex instead of the plain 2x box).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,8 +48,9 @@ static void make_torus(int nu, int nv, std::vector<Vector3>& v, std::vector<int>
 
 int main(int argc, char** argv)
 {
-    std::string mesh = "cube", obj;
+    std::string mesh = "cube", obj, obj_in;
     int cells = 8, nu = 250, nv = 200;
+    bool ach = false; float in_scale = 1.f;
     for (int i = 1; i < argc; ++i)
     {
         if (!strcmp(argv[i], "--mesh") && i + 1 < argc) mesh = argv[++i];
@@ -56,12 +58,17 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--nu") && i + 1 < argc) nu = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--nv") && i + 1 < argc) nv = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--obj") && i + 1 < argc) obj = argv[++i];
+        else if (!strcmp(argv[i], "--obj-in") && i + 1 < argc) { obj_in = argv[++i]; mesh = obj_in; }
+        else if (!strcmp(argv[i], "--scale") && i + 1 < argc) in_scale = (float)atof(argv[++i]);
+        else if (!strcmp(argv[i], "--ach")) ach = true;
     }
     try
     {
         std::vector<Vector3> verts; std::vector<int> tris;
-        if (mesh == "torus") make_torus(nu, nv, verts, tris); else make_cube(verts, tris);
-        // PrepareFracture steps 3, 5, 7, 8 (Src/Surtr.cpp:1757-1803); the k-DOP clip of step 6 is not applied yet
+        if (!obj_in.empty()) LoadModelData(obj_in, Vector3(in_scale, in_scale, in_scale), Vector3(0, 0, 0), verts, tris);
+        else if (mesh == "torus") make_torus(nu, nv, verts, tris);
+        else make_cube(verts, tris);
+        // PrepareFracture steps 3, 5, 7, 8 (Src/Surtr.cpp:1757-1803); with --ach the whole routine incl. the k-DOP clip of step 6
         Vector3 lo = verts[0], hi = verts[0];
         for (auto& p : verts) { lo.x = std::min(lo.x, p.x); hi.x = std::max(hi.x, p.x); lo.y = std::min(lo.y, p.y); hi.y = std::max(hi.y, p.y); lo.z = std::min(lo.z, p.z); hi.z = std::max(hi.z, p.z); }
         const Vector3 ext(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z);
@@ -77,11 +84,16 @@ int main(int argc, char** argv)
         for (int i = 0; i < cells; ++i) { double x = u(gen), y = u(gen), z = u(gen); seeds.emplace_back((float)x, (float)y, (float)z); }
 
         FractureEngine eng(0);
-        eng.SetPattern(FractureEngine::GenerateVoronoi(seeds));
-        eng.PlacePattern(ext, cen);
-        Compound comp; comp.PieceVec.push_back(piece);
-        eng.SetCompound(comp);
-        std::vector<Fragment> frags = eng.ApplyFracture();
+        std::vector<Fragment> frags;
+        if (ach) frags = eng.PrepareFracture(verts, tris, seeds);
+        else
+        {
+            eng.SetPattern(FractureEngine::GenerateVoronoi(seeds));
+            eng.PlacePattern(ext, cen);
+            Compound comp; comp.PieceVec.push_back(piece);
+            eng.SetCompound(comp);
+            frags = eng.ApplyFracture();
+        }
         const surtr_counts c = eng.LastCounts();
         printf("{\"mesh\": \"%s\", \"verts\": %zu, \"tris\": %zu, \"cells\": %d, \"fragments\": %u, \"mesh_verts\": %u, \"mesh_nbrs\": %u, "
                "\"conv_verts\": %u, \"indices\": %u}\n", mesh.c_str(), verts.size(), tris.size() / 3, cells, c.n_frag, c.mesh_verts,

@@ -1,6 +1,7 @@
 // surtr_host.cpp -- see surtr_host.hpp.  Flatten -> C ABI -> rebuild; no geometry here.
 #include "surtr_host.hpp"
 
+#include <algorithm>
 #include <cstring>
 
 namespace surtr {
@@ -75,6 +76,67 @@ std::vector<std::vector<int>> Poly::ExtractNeighborFromMesh(std::vector<Vector3>
 
 FractureEngine::FractureEngine(int device) { check(surtr_create(device, &ctx_), "surtr_create"); }
 FractureEngine::~FractureEngine() { surtr_destroy(ctx_); }
+
+void LoadModelData(const std::string& fileName, const Vector3& scale, const Vector3& translate, std::vector<Vector3>& vertices,
+                   std::vector<int>& indices)
+{
+    const float sc[3] = {scale.x, scale.y, scale.z}, tr[3] = {translate.x, translate.y, translate.z};
+    uint32_t nv = 0, nt = 0;
+    int rc = surtr_read_obj(fileName.c_str(), sc, tr, 0, 0, nullptr, nullptr, &nv, &nt);
+    if (rc) throw Error(rc, "LoadModelData: cannot read " + fileName);
+    std::vector<float> pos(3 * (size_t)nv + 3); std::vector<int32_t> tri(3 * (size_t)nt + 3);
+    rc = surtr_read_obj(fileName.c_str(), sc, tr, nv, nt, pos.data(), tri.data(), &nv, &nt);
+    if (rc) throw Error(rc, "LoadModelData: cannot read " + fileName);
+    vertices.resize(nv); indices.assign(tri.begin(), tri.begin() + 3 * (size_t)nt);
+    for (uint32_t v = 0; v < nv; ++v) vertices[v] = Vector3(pos[3 * v], pos[3 * v + 1], pos[3 * v + 2]);
+}
+
+Poly::Polyhedron FractureEngine::BuildACH(const std::vector<Vector3>& vertices, uint32_t ichIncludePointLimit, float achPlaneGapInverse)
+{
+    if (vertices.empty()) throw Error(SURTR_E_INVALID, "BuildACH: no vertices");
+    std::vector<float> pts; pts.reserve(3 * vertices.size());
+    Vector3 lo = vertices[0], hi = vertices[0];
+    for (const auto& p : vertices)
+    {
+        pts.push_back(p.x); pts.push_back(p.y); pts.push_back(p.z);
+        lo.x = std::min(lo.x, p.x); hi.x = std::max(hi.x, p.x); lo.y = std::min(lo.y, p.y); hi.y = std::max(hi.y, p.y);
+        lo.z = std::min(lo.z, p.z); hi.z = std::max(hi.z, p.z);
+    }
+    // steps 1-2: ICH face normals
+    std::vector<float> nrm(3 * (size_t)(2 * ichIncludePointLimit + 8));
+    uint32_t k = 0;
+    check(surtr_hull_normals((uint32_t)vertices.size(), pts.data(), ichIncludePointLimit, (uint32_t)(nrm.size() / 3), nrm.data(), &k), "surtr_hull_normals");
+    // steps 3-4: bounding box, k-DOP min/max planes
+    const double maxAxis = std::max(std::max((double)hi.x - lo.x, (double)hi.y - lo.y), (double)hi.z - lo.z);
+    std::vector<float> pl(8 * (size_t)k);
+    check(surtr_kdop_ach_planes((uint32_t)vertices.size(), pts.data(), k, nrm.data(), maxAxis, achPlaneGapInverse, pl.data()), "surtr_kdop_ach_planes");
+    // steps 5-6: 2x box, clipped by every plane
+    Poly::Polyhedron box = Poly::GetBB();
+    Poly::Scale(box, Vector3(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z)); Poly::Scale(box, Vector3(2, 2, 2));
+    Poly::Translate(box, Vector3((float)(((double)hi.x + lo.x) / 2.0), (float)(((double)hi.y + lo.y) / 2.0), (float)(((double)hi.z + lo.z) / 2.0)));
+    std::vector<Plane> planes(2 * (size_t)k);
+    for (size_t i = 0; i < planes.size(); ++i) { planes[i].x = pl[4 * i]; planes[i].y = pl[4 * i + 1]; planes[i].z = pl[4 * i + 2]; planes[i].w = pl[4 * i + 3]; }
+    return ClipPolyhedron(box, planes);
+}
+
+std::vector<Fragment> FractureEngine::PrepareFracture(std::vector<Vector3>& vertices, std::vector<int>& indices, const std::vector<Vector3>& cellPointVec)
+{
+    Piece piece;
+    piece.Convex = BuildACH(vertices);
+    Poly::InitPolyhedron(piece.Mesh, vertices, Poly::ExtractNeighborFromMesh(vertices, indices));      // step 7
+    Vector3 lo = vertices[0], hi = vertices[0];
+    for (const auto& p : vertices)
+    {
+        lo.x = std::min(lo.x, p.x); hi.x = std::max(hi.x, p.x); lo.y = std::min(lo.y, p.y); hi.y = std::max(hi.y, p.y);
+        lo.z = std::min(lo.z, p.z); hi.z = std::max(hi.z, p.z);
+    }
+    SetPattern(GenerateVoronoi(cellPointVec));                                                          // step 8
+    PlacePattern(Vector3(hi.x - lo.x, hi.y - lo.y, hi.z - lo.z),
+                 Vector3((float)(((double)hi.x + lo.x) / 2.0), (float)(((double)hi.y + lo.y) / 2.0), (float)(((double)hi.z + lo.z) / 2.0)));
+    Compound comp; comp.PieceVec.push_back(piece);
+    SetCompound(comp);
+    return ApplyFracture();                                                                             // step 10 (+ Refitting, SetExtract)
+}
 
 void FractureEngine::check(int rc, const char* what)
 {

@@ -58,6 +58,11 @@ struct Polygon3D                                // Inc/VMACH.h:60-86
 };
 } // namespace VMACH
 
+// Surtr::LoadModelData (Src/Surtr.cpp:2683-2727) for Wavefront OBJ: positions with x negated, scaled, translated; triangles
+// with the winding flipped; identical positions joined (normals are not read: the path does not use them).
+void LoadModelData(const std::string& fileName, const Vector3& scale, const Vector3& translate, std::vector<Vector3>& vertices,
+                   std::vector<int>& indices);
+
 struct Piece { Poly::Polyhedron Convex, Mesh; };            // Inc/Surtr.h:113-119
 struct Compound { std::vector<Piece> PieceVec; };           // Inc/Surtr.h:121-127 (value semantics: no leaks)
 
@@ -84,6 +89,12 @@ public:
     // fragments in cell-major, piece, island order.
     std::vector<Fragment> ApplyFracture(const std::set<int>& outside = {}, bool refit = true, bool render = true,
                                         uint32_t cellBegin = 0, uint32_t cellEnd = 0xFFFFFFFFu);
+    // Steps 1-6 of Surtr::PrepareFracture (Src/Surtr.cpp:1750-1785): ICH(limit) face normals -> k-DOP slabs moved out by
+    // MaxAxisScale / planeGapInverse -> the 2x bounding box clipped by all of them (the approximate convex hull).
+    Poly::Polyhedron BuildACH(const std::vector<Vector3>& vertices, uint32_t ichIncludePointLimit = 20, float achPlaneGapInverse = 2000.f);
+    // Surtr::PrepareFracture (Src/Surtr.cpp:1747-1827) from a raw triangle mesh: ACH, neighbour rings, `cellCnt` Voronoi cells
+    // placed over the bounding box, one event with refit + extraction.  Returns the pieces of the initial compound.
+    std::vector<Fragment> PrepareFracture(std::vector<Vector3>& vertices, std::vector<int>& indices, const std::vector<Vector3>& cellPointVec);
     // Poly::ClipPolyhedron(polyhedron, polygon3D), Src/Poly.cpp:556-566.
     Poly::Polyhedron ClipPolyhedron(const Poly::Polyhedron& polyhedron, const VMACH::Polygon3D& polygon3D);
     Poly::Polyhedron ClipPolyhedron(const Poly::Polyhedron& polyhedron, const std::vector<Plane>& planes);

@@ -48,8 +48,7 @@ def pattern_seeds(n, mean, seed=SEED):
 
 def box_solid(extent, center, factor=2.0):
     """Poly::GetBB scaled by the AABB extent and by 2, translated to the AABB centre
-    (PrepareFracture steps 5, Src/Surtr.cpp:1779-1782).  The k-DOP clip of step 6 is not applied
-    (ACH construction is row f2 of SURVEY.md section 8 and not built yet)."""
+    (PrepareFracture step 5, Src/Surtr.cpp:1779-1782); ach_convex() applies the k-DOP clip of step 6."""
     p = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5],
                   [-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]], np.float32)
     nb = np.array([[1, 4, 3], [5, 0, 2], [3, 6, 1], [7, 2, 0], [5, 7, 0], [1, 6, 4], [5, 2, 7], [4, 6, 3]], np.int32)
@@ -136,3 +135,19 @@ def ach_convex(eng, verts):
     max_axis = float(max(float(hi[0]) - float(lo[0]), float(hi[1]) - float(lo[1]), float(hi[2]) - float(lo[2])))
     planes = engine.kdop_ach_planes(v, normals, max_axis, ACH_PLANE_GAP_INV)
     return eng.clip_polyhedron(box_solid(extent, center), planes), planes
+
+
+def prepare_fracture(eng, verts, tris, n_cells=64, seed=SEED, flags=engine.EVT_REFIT | engine.EVT_RENDER):
+    """Surtr::PrepareFracture end to end (Src/Surtr.cpp:1747-1827) from a raw triangle mesh: ICH(20) normals ->
+    k-DOP slabs -> ACH = clipped 2x box (steps 1-6), neighbour rings of the mesh (7), `n_cells` Voronoi cells scaled by
+    the AABB extent and centred (8), one fracture event of the single piece (Mesh, ACH) with refit and extraction (10).
+    Returns (scene, counts, fragments); scenes.fragments_as_pieces(fragments) gives the pieces of the initial compound
+    in the reference's order (bind 0 is empty, then one bind per cell: cell-major = fragment order)."""
+    v = np.ascontiguousarray(verts, np.float32)
+    sc = make_scene(v, np.ascontiguousarray(tris, np.int32), n_cells, seeds=uniform_seeds(n_cells, seed))
+    sc["convex"], sc["ach_planes"] = ach_convex(eng, v)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    counts = eng.fracture_event(0, n_cells, flags=flags)
+    return sc, counts, eng.download()

@@ -5,7 +5,7 @@ import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from helpers import assert_event_equal, fragment, run_event
-from surtr_amd import scenes
+from surtr_amd import meshgen, scenes
 
 
 @pytest.mark.parametrize("flags", [0, 1, 2, 3])
@@ -208,3 +208,33 @@ def test_event_with_ach_convex(emul_engine, oracle):
     eng.close()
     c, got, ref = run_event(emul_engine, oracle, sc, 3, cells=48)
     assert_event_equal(got, ref)
+
+
+def _oracle_prepare(oracle, v, t, n_cells, seed):
+    """PrepareFracture restated with the oracle's pieces only (Src/Surtr.cpp:1747-1827)."""
+    lo, hi = v.min(0), v.max(0)
+    ext = (hi - lo).astype(np.float32)
+    ctr = ((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32)
+    nrm = oracle.hull_normals(v, 20)
+    pl = oracle.kdop_planes(v, nrm, ach=True, max_axis_scale=float(max(float(hi[a]) - float(lo[a]) for a in range(3))), gap_inv=2000.0)
+    ach = oracle.clip(scenes.box_solid(ext, ctr), pl)
+    mesh = oracle.neighbours_from_mesh(v, t)
+    cells = oracle.voronoi_cells(oracle.seeds(n_cells, seed))
+    return ach, mesh, cells, ext, ctr
+
+
+def test_prepare_fracture_end_to_end(emul_engine, oracle):
+    """Row f2: raw mesh in, initial compound out, against the oracle restatement of every step."""
+    v, t = meshgen.blob(2, scale=3.0)
+    eng = emul_engine.Engine(0)
+    sc, c, got = scenes.prepare_fracture(eng, v, t, n_cells=12, seed=4711)
+    ach, mesh, cells, ext, ctr = _oracle_prepare(oracle, v, t, 12, 4711)
+    assert np.array_equal(sc["convex"]["nbr"], ach["nbr"]) and np.allclose(sc["convex"]["pos"], ach["pos"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(sc["mesh"]["nbr"], mesh["nbr"])
+    planes = oracle.place_cells(sc["v012"], ext, ctr)
+    ref = oracle.event([mesh], [ach], sc["face_off"], planes, refit=True, render=True, threads=2)
+    assert c.status == 0 and c.n_frag >= 8
+    assert_event_equal(got, ref)
+    meshes, convexes = scenes.fragments_as_pieces(got)
+    assert len(meshes) == c.n_frag == len(convexes)
+    eng.close()

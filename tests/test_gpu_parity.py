@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from helpers import RTOL, assert_event_equal, fragment, run_event
-from surtr_amd import scenes
+from surtr_amd import meshgen, scenes
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -195,6 +195,24 @@ def test_cpp_host_layer_and_harness(gpu_engine, oracle):
     ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, threads=8)
     assert out["fragments"] == ref["frag_ids"].shape[0] and out["mesh_verts"] == ref["mesh_pos"].shape[0]
     assert out["indices"] == ref["idx"].shape[0] and out["mesh_nbrs"] == ref["mesh_nbr"].shape[0]
+    # rows f2 + f3: a mesh file in (LoadModelData conventions), PrepareFracture end to end (--ach), fragments out as OBJ
+    import tempfile
+    v, t = meshgen.blob(3, scale=2.0)
+    with tempfile.TemporaryDirectory() as d:
+        src, dst = os.path.join(d, "in.obj"), os.path.join(d, "out.obj")
+        with open(src, "w") as f:
+            for a in v:
+                f.write("v %.9g %.9g %.9g\n" % (-a[0], a[1], a[2]))
+            for a, b, c in t:
+                f.write("f %d %d %d\n" % (c + 1, b + 1, a + 1))
+        out = js.loads(subprocess.check_output([exe, "--obj-in", src, "--cells", "16", "--ach", "--obj", dst]).decode().strip().splitlines()[-1])
+        rv, rt = gpu_engine.read_obj(src)
+        eng = gpu_engine.Engine(0)
+        sc, c, got = scenes.prepare_fracture(eng, rv, rt, n_cells=16)
+        eng.close()
+        assert out["fragments"] == c.n_frag and out["mesh_verts"] == c.mesh_verts and out["indices"] == c.n_idx and out["conv_verts"] == c.conv_verts
+        text = open(dst).read()
+        assert text.count("\no ") + 1 == c.n_frag and text.count("\nf ") == c.n_idx // 3
 
 
 def test_torus_with_ach_convex(gpu_engine, oracle):
@@ -208,3 +226,20 @@ def test_torus_with_ach_convex(gpu_engine, oracle):
     c, got, ref = run_event(gpu_engine, oracle, sc, 3, threads=16)
     assert c.status == 0
     assert_event_equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_prepare_fracture_end_to_end_gpu(gpu_engine, oracle):
+    """Row f2 on the GPU: PrepareFracture (Src/Surtr.cpp:1747-1827) of a 2 562-vertex blob into 64 cells."""
+    v, t = meshgen.blob(4, scale=70.0)
+    eng = gpu_engine.Engine(0)
+    sc, c, got = scenes.prepare_fracture(eng, v, t, n_cells=64)
+    lo, hi = v.min(0), v.max(0)
+    nrm = oracle.hull_normals(v, 20)
+    pl = oracle.kdop_planes(v, nrm, ach=True, max_axis_scale=float(max(float(hi[a]) - float(lo[a]) for a in range(3))), gap_inv=2000.0)
+    ach = oracle.clip(scenes.box_solid(sc["scale"], sc["translate"]), pl)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([oracle.neighbours_from_mesh(v, t)], [ach], sc["face_off"], planes, refit=True, render=True, threads=8)
+    assert c.status == 0 and c.n_frag >= 48
+    assert_event_equal(got, ref)
+    eng.close()

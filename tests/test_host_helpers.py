@@ -87,3 +87,64 @@ def test_cell_planes_point_outward(oracle):
         p = planes[sc["face_off"][c]:sc["face_off"][c + 1]]
         seed = (sc["seeds"][c] * sc["scale"] + sc["translate"]).astype(np.float32)
         assert np.all(p[:, :3] @ seed + p[:, 3] < 0)
+
+
+def test_moments_matches_oracle_and_partitions(oracle):
+    """Row A14: Poly::Moments (Src/Poly.cpp:55-87) on the host = the oracle's; box KAT from SURVEY (volume 0.5)."""
+    from surtr_amd import engine, meshgen, scenes
+    box = oracle.unit_box()
+    v, c = engine.moments(box)
+    assert abs(v - 1.0) < 1e-6 and np.allclose(c, 0.0, atol=1e-6)
+    half = oracle.clip(box, np.float32([[1, 1, 1, 0]]))
+    v, c = engine.moments(half)
+    ov, oc = oracle.moments(half)
+    assert v == ov and np.array_equal(c, oc.astype(np.float32))
+    assert abs(v - 0.5) < 1e-6 and np.allclose(c, -0.135417, atol=1e-5)
+    vb, tb = meshgen.blob(2, scale=3.0)
+    mesh = engine.neighbors_from_mesh(vb, tb)
+    v, c = engine.moments(mesh)
+    ov, oc = oracle.moments(mesh)
+    assert v == ov and np.array_equal(c, oc.astype(np.float32))
+
+
+def test_obj_reader_conventions_and_writer(tmp_path):
+    """Row f3: OBJ in with the reference's load conventions (x negated, winding flipped, identical positions joined,
+    Src/Surtr.cpp:2683-2727) and fragments out as OBJ."""
+    from surtr_amd import engine, meshgen
+    v, t = meshgen.blob(2, scale=3.0)
+    p = tmp_path / "blob.obj"
+    with open(p, "w") as f:
+        f.write("# test\n")
+        for a in v:
+            f.write("v %.9g %.9g %.9g\n" % (-a[0], a[1], a[2]))          # pre-mirrored, so that the reader gives v back
+        for a, b, c in t:
+            f.write("f %d/1/1 %d//2 %d\n" % (c + 1, b + 1, a + 1))       # pre-flipped, corners with /vt/vn decorations
+        f.write("v 9 9 9\n")                                            # unused vertex: not emitted
+    rv, rt = engine.read_obj(str(p))
+    # vertices come back in order of first use by a face, triangles in file order
+    order = []
+    seen = set()
+    for tri in t[:, ::-1]:
+        for i in tri:
+            if int(i) not in seen:
+                seen.add(int(i)); order.append(int(i))
+    assert rv.shape[0] == len(order) and rt.shape == t.shape
+    assert np.array_equal(rv, v[order])
+    inv = np.empty(len(order), np.int64); inv[order] = np.arange(len(order))
+    assert np.array_equal(rt, inv[t])
+    # the mesh is closed and consistently wound: the neighbour extraction accepts it
+    mesh = engine.neighbors_from_mesh(rv, rt)
+    assert engine.moments(mesh)[0] > 0
+    # scale / translate, negative indices, quads as fans
+    q = tmp_path / "quad.obj"
+    q.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf -4 -3 -2 -1\n")
+    qv, qt = engine.read_obj(str(q), scale=(2, 2, 2), translate=(1, 0, 0))
+    assert np.array_equal(qv, np.float32([[1, 0, 0], [-1, 0, 0], [-1, 2, 0], [1, 2, 0]]))
+    assert np.array_equal(qt, np.int32([[2, 1, 0], [3, 2, 0]]))
+    # writer: one object per fragment, 1-based indices continuing across objects
+    fr = {"frag_ids": np.int32([[0, 0, 0], [1, 0, 0]]), "mesh_vert_off": np.uint32([0, 3, 6]),
+          "vnc": np.arange(54, dtype=np.float32).reshape(6, 9), "idx_off": np.uint32([0, 3, 6]), "idx": np.uint32([0, 1, 2, 0, 2, 1])}
+    w = tmp_path / "out.obj"
+    engine.write_obj(str(w), fr)
+    lines = w.read_text().splitlines()
+    assert lines[0] == "o cell0_piece0_island0" and lines[4] == "f 1 2 3" and lines[5] == "o cell1_piece0_island0" and lines[9] == "f 4 6 5"
