@@ -82,7 +82,9 @@ __device__ unsigned long long g_stamp[80];
 #endif
 #endif
 #define SURTR_NEVER 0xFFu       // fc of a vertex no plane clips
-#define SURTR_WALK0 12u        // walk steps before the cap-run shortcut is built
+#ifndef SURTR_WALK0
+#define SURTR_WALK0 6u         // walk steps before the cap-run shortcut is built
+#endif
 #define SURTR_OVERFLOW 100       // internal: the solid does not fit this Topo, redo with the larger one
 
 // LDS-resident topology: capacities per workgroup
@@ -1054,6 +1056,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             // which (clipped vertex, slot) makes new vertex n0 + t, in reference order
             uint32_t* srcv = T.succ; uint32_t* srcj = T.pred;
             const uint32_t nb = (nC + SURTR_LANES - 1u) >> SURTR_LSH;
+            bool dup = false;
             for (uint32_t b = w; b < nb; b += group_waves())
             {
                 const uint32_t first = T.blk[b].x, beyond = (b + 1u < nb) ? T.blk[b + 1u].x : M;
@@ -1073,14 +1076,20 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                         const uint32_t u = r[j];
                         if (u >= TT::SENT || T.cmp(u) <= 0) continue;
                         srcv[t] = v; srcj[t] = j; ++t;
+                        // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
+                        for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u) dup = true;
                     }
                 }
             }
+            if (dup) pf[3] = 1;
             __syncthreads();
             STAMP(9);
-            // dense pass: one lane per new vertex (two position gathers each, all lanes busy)
-            uint32_t* keptof = T.aux1;     // kept end of every new vertex, for the back-link patch below
-            bool dup = false;
+            const bool ordered = pf[3] != 0;
+            // dense pass: one lane per new vertex (two position gathers each, all lanes busy); unless the order matters,
+            // the lane also patches the links of the two ends (:350-354): "find the clipped vertex in the kept vertex's
+            // ring, overwrite it" -- concurrent patches touch different entries, and an entry already patched holds a new
+            // vertex, which no search looks for
+            uint32_t* keptof = T.aux1;     // kept end of every new vertex
             for (uint32_t t = tid; t < M; t += group_size())
             {
                 const uint32_t v = srcv[t], j = srcj[t], fresh = n0 + t;
@@ -1113,26 +1122,17 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 T.ring[lo] = (I)v; T.ring[lo + 1] = (I)u; T.ring[lo + 2] = (I)TT::REM;
                 keptof[t] = u;
                 T.pcnt[t] = 0;             // predecessor count of the relink below
-                // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
-                for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u) dup = true;
-            }
-            if (dup) pf[3] = 1;
-            __syncthreads();
-            STAMP(10);
-            const bool ordered = pf[3] != 0;
-            // links of the two ends (:350-354): "find the clipped vertex in the kept vertex's ring, overwrite it"
-            if (!ordered)
-            {
-                for (uint32_t t = tid; t < M; t += group_size())
+                if (!ordered)
                 {
-                    const uint32_t v = srcv[t], u = keptof[t], fresh = n0 + t;
                     I* ru = T.ring + T.loff[u];
                     const uint32_t du = T.llen[u];
                     for (uint32_t q = 0; q < du; ++q) if ((uint32_t)ru[q] == v) { ru[q] = (I)fresh; break; }
-                    T.ring[T.loff[v] + srcj[t]] = (I)fresh;
+                    r[j] = (I)fresh;
                 }
             }
-            else if (tid == 0)
+            STAMP(10);
+            if (ordered) __syncthreads();
+            if (ordered && tid == 0)
             {
                 COUNT(39);
                 for (uint32_t t = 0; t < M; ++t)        // reference order: first remaining occurrence each time
