@@ -1180,13 +1180,19 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             {
                 const uint32_t X = n0 + t;
                 uint32_t prev = X, c = T.ring[T.loff[X]], steps = 0;
-                while (c < TT::SENT && T.cmp(c) == -1 && steps < SURTR_WALK0)
+                bool clipped;
+                while (true)
                 {
+                    // state, ring offset and length of c in one LDS round trip (index clamped: c may be a sentinel)
+                    const uint32_t cc = c < TT::SENT ? c : 0u;
+                    const int cm = T.cmp(cc); const uint32_t lo = T.loff[cc], len = T.llen[cc];
+                    clipped = c < TT::SENT && cm == -1;
+                    if (!clipped || steps >= SURTR_WALK0) break;
                     const uint32_t hold = c;
-                    c = face_next(T.ring + T.loff[c], T.llen[c], prev);
+                    c = face_next(T.ring + lo, len, prev);
                     prev = hold; ++steps;
                 }
-                if (c < TT::SENT && T.cmp(c) == -1) { wsave[t] = prev | 0x80000000u; T.succ[t] = c; longw = true; continue; }
+                if (clipped) { wsave[t] = prev | 0x80000000u; T.succ[t] = c; longw = true; continue; }
                 wsave[t] = 0;
                 finish(t, X, c);
             }
@@ -1232,10 +1238,12 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     if (!(w0 & 0x80000000u)) continue;
                     const uint32_t X = n0 + t;
                     uint32_t prev = w0 & 0x7fffffffu, c = T.succ[t], steps = SURTR_WALK0;
-                    while (c < TT::SENT && T.cmp(c) == -1 && steps++ < n1)
+                    while (true)
                     {
-                        const I* r = T.ring + T.loff[c];
-                        const uint32_t len = T.llen[c];
+                        const uint32_t cc = c < TT::SENT ? c : 0u;
+                        const int cm = T.cmp(cc); const uint32_t lo = T.loff[cc], len = T.llen[cc];
+                        if (!(c < TT::SENT && cm == -1 && steps++ < n1)) break;
+                        const I* r = T.ring + lo;
                         if (len == 3u && (uint32_t)r[1] == prev && (uint32_t)r[0] != prev)
                         {
                             const uint32_t e = jump[c];
