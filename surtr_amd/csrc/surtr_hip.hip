@@ -729,7 +729,8 @@ __device__ static void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Piec
 #endif
 }
 
-__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
+// two workgroups per CU = two waves per SIMD: the register budget must stay within 256 VGPRs
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
                                                          ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
