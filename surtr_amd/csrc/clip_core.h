@@ -1070,8 +1070,19 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             cutcnt.set(i, c);
             return make_uint2(c, 1u);
         };
-        uint32_t M = 0, nCut = 0;
-        scan_blocks(nC, T.blk, sh, cutfn, M, nCut);
+        // every wave counts a contiguous range of 64-vertex blocks of the clipped list: one barrier gives M and, in the
+        // sweep below, the wave's base
+        const uint32_t cnb = (nC + SURTR_LANES - 1u) >> SURTR_LSH, cnbw = (cnb + group_waves() - 1u) / group_waves();
+        const uint32_t cb0 = w * cnbw, cb1 = cb0 + cnbw < cnb ? cb0 + cnbw : cnb;
+        uint32_t M = 0;
+        {
+            uint32_t mine = 0;
+            for (uint32_t b = cb0; b < cb1; ++b) { const uint32_t i = (b << SURTR_LSH) + l; if (i < nC) mine += cutfn(i).x; }
+            const uint2 inc = wave_incl_scan2(make_uint2(mine, 0u));
+            if (l == SURTR_LANES - 1u) sh.wsum[w] = inc.x;
+            __syncthreads();
+            for (uint32_t q = 0; q < group_waves(); ++q) M += sh.wsum[q];
+        }
         STAMP(8);
         // An in-plane plane takes the serial relink, which re-homes the rings of in-plane vertices (room for the walks
         // that arrive + the old_neighbors snapshot): about 4 entries per ring entry of an in-plane vertex.  New vertices
@@ -1111,20 +1122,25 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         const WArr<uint16_t> wsave = carve16(M, wfloor, T.aux0);
         {
             // which (clipped vertex, slot) makes new vertex n0 + t, in reference order
-            const uint32_t nb = (nC + SURTR_LANES - 1u) >> SURTR_LSH;
             bool dup = false;
-            for (uint32_t b = w; b < nb; b += group_waves())
+            uint32_t run = 0;
+            for (uint32_t q = 0; q < w; ++q) run += sh.wsum[q];
+            for (uint32_t b = cb0; b < cb1; ++b)
             {
-                const uint32_t first = T.blk[b].x, beyond = (b + 1u < nb) ? T.blk[b + 1u].x : M;
-                if (first == beyond) continue;
                 const uint32_t i = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
                 if (i < nC) c.x = cutcnt.get(i);
-                const uint2 e = wave_excl2(c);
+                const uint2 s2 = wave_incl_scan2(c);
+                const uint32_t base = run;
+#ifdef SURTR_EMUL
+                run += s2.x;
+#else
+                run += (uint32_t)__shfl((int)s2.x, SURTR_LANES - 1, SURTR_LANES);
+#endif
                 if (i < nC && c.x)
                 {
                     const uint32_t v = clist.get(i);
-                    uint32_t t = T.blk[b].x + e.x;
+                    uint32_t t = base + s2.x - c.x;
                     const I* r = T.ring + T.loff[v];
                     const uint32_t deg = T.llen[v];
                     for (uint32_t j = 0; j < deg; ++j)
