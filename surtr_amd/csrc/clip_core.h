@@ -1143,13 +1143,23 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                     uint32_t t = base + s2.x - c.x;
                     const I* r = T.ring + T.loff[v];
                     const uint32_t deg = T.llen[v];
-                    for (uint32_t j = 0; j < deg; ++j)
+                    for (uint32_t j0 = 0; j0 < deg; j0 += 4)
                     {
-                        const uint32_t u = r[j];
-                        if (u >= TT::SENT || T.cmp(u) <= 0) continue;
-                        srcv.set(t, v); srcj.set(t, j); ++t;
-                        // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
-                        for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u) dup = true;
+                        // four entries per round trip, as in the count (indices clamped into the ring)
+                        uint32_t u[4]; int cu[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) u[q] = r[j0 + q < deg ? j0 + q : deg - 1u];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) cu[q] = T.cmp(u[q] < TT::SENT ? u[q] : 0u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            const uint32_t j = j0 + q;
+                            if (j >= deg || u[q] >= TT::SENT || cu[q] <= 0) continue;
+                            srcv.set(t, v); srcj.set(t, j); ++t;
+                            // a ring that lists the same kept neighbour twice (sliver input) makes the back-link patch order dependent
+                            for (uint32_t jj = 0; jj < j; ++jj) if ((uint32_t)r[jj] == u[q]) dup = true;
+                        }
                     }
                 }
             }
