@@ -17,7 +17,7 @@ L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
 names = ["pre: A1 stream", "pre: A2 exact", "pre: emit", "pre: A3 block counts + scan", "plane: classify", "plane: cut links patch", "plane: relink finalize/serial", "plane: tombstones",
-         "plane: cut scan", "plane: cut sparse sweep", "plane: cut dense create", "plane: chain jump", "plane: walks (first 12 steps)", "plane: pred check", "plane: resumed walks"]
+         "plane: cut scan", "plane: cut sparse sweep", "plane: cut dense create", "plane: chain jump", "plane: walks (first steps)", "plane: pred check", "plane: resumed walks"]
 tot = sum(buf[i] for i in range(15))
 for i, n in enumerate(names):
     print("%-20s %14d  %5.1f%%" % (n, buf[i], 100.0 * buf[i] / max(tot, 1)))
