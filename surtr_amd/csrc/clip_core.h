@@ -74,6 +74,14 @@ __device__ unsigned long long g_stamp[80];
 #else
 #define SURTR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 #endif
+// vertices per bounding sphere of the spatially sorted copy (pre-pass A0); a wave of A1 takes LANES / SB undecided groups
+#ifdef SURTR_EMUL
+#define SURTR_SB 1u
+#else
+#ifndef SURTR_SB
+#define SURTR_SB 8u
+#endif
+#endif
 #ifndef SURTR_KEEPALL_V
 #ifdef SURTR_EMUL
 #define SURTR_KEEPALL_V 12u     // (emulation: small, so that the tests still run the culling on small meshes)
@@ -187,7 +195,7 @@ struct SolidIn
     const uint8_t* tri;     // per vertex: 1 = every incident face is a triangle (nullptr = unknown)
     const float* rad;       // per vertex: radius of a ball around it holding every vertex of its incident faces (nullptr = unknown)
     // spatially sorted copy for the pre-pass (nullptr = absent): sorted index i is vertex perm[i]; bsph[b] bounds
-    // the balls of the 64 vertices of sorted block b (centre xyz, radius w)
+    // the balls of the SURTR_SB vertices of sorted group b (centre xyz, radius w)
     const uint32_t* perm; const float* pos_s; const float* rad_s; const float4* bsph;
 };
 
@@ -473,17 +481,18 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     // If the ball that holds every vertex of v's incident faces stays strictly on v's side of every plane up
     // to and including fc(v), all those vertices have the same fc and v is dropped right here.
     const bool sorted = in.bsph != nullptr && in.perm != nullptr && V < (1u << 24);
-    uint32_t nWork = nbV;                 // 64-blocks that need the per-vertex pass
+    uint32_t nWork = nbV, nUnd = 0;       // wave-loads (64 vertices) that need the per-vertex pass; undecided groups
     // und: (sorted path) the blocks the sphere test could not decide
     if (sorted)
     {
-        // ---- A0: one lane per block of 64 spatially close vertices: if the sphere around their balls is entirely on
+        // ---- A0: one lane per group of SURTR_SB spatially close vertices: if the sphere around their balls is entirely on
         // the cut side of plane k and entirely on the kept side of planes 0..k-1, all of them have fc = k and every one
-        // is dropped (same argument as the per-vertex ball test); nothing of the block is read.
+        // is dropped (same argument as the per-vertex ball test); nothing of the group is read.
         for (uint32_t bq = tid; bq < nbV; bq += group_size()) bmask[bq] = 0ull;
         if (tid == 0) sh.misc[4] = 0;
         __syncthreads();
-        for (uint32_t sb = tid; sb < nbV; sb += group_size())
+        const uint32_t nsb = (V + SURTR_SB - 1u) / SURTR_SB;
+        for (uint32_t sb = tid; sb < nsb; sb += group_size())
         {
             const float4 sp = in.bsph[sb];
             const float mag = fabsf(sp.x) + fabsf(sp.y) + fabsf(sp.z) + sp.w;
@@ -498,15 +507,16 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             }
             if (f != 0xFFu)
             {
-                const uint32_t left = V - (sb << SURTR_LSH);
-                atomicAdd(&sh.hist[f], left < SURTR_LANES ? left : (uint32_t)SURTR_LANES);
+                const uint32_t left = V - sb * SURTR_SB;
+                atomicAdd(&sh.hist[f], left < SURTR_SB ? left : (uint32_t)SURTR_SB);
             }
             else und[atomicAdd(&sh.misc[4], 1u)] = sb;
         }
         __syncthreads();
-        nWork = sh.misc[4];
+        nUnd = sh.misc[4];
+        nWork = (nUnd + SURTR_LANES / SURTR_SB - 1u) / (SURTR_LANES / SURTR_SB);     // wave-loads of undecided groups
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-        if (tid == 0 && V > 10000u) { atomicAdd(&g_stamp[45], (unsigned long long)nWork); atomicAdd(&g_stamp[46], (unsigned long long)nbV); }
+        if (tid == 0 && V > 10000u) { atomicAdd(&g_stamp[45], (unsigned long long)nUnd); atomicAdd(&g_stamp[46], (unsigned long long)nsb); }
 #endif
     }
     for (uint32_t b0 = w; b0 < nWork; b0 += (uint32_t)G * group_waves())
@@ -519,9 +529,16 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
         for (int g = 0; g < G; ++g)
         {
             const uint32_t wb = b0 + g * group_waves();
-            const uint32_t blk = (sorted && wb < nWork) ? und[wb] : wb;
-            const uint32_t i = (blk << SURTR_LSH) + l;
-            valid4[g] = wb < nWork && i < V;
+            uint32_t i = (wb << SURTR_LSH) + l;
+            bool ok = wb < nWork;
+            if (sorted)
+            {
+                // lane l reads vertex l % SB of the (l / SB)-th undecided group of this wave-load
+                const uint32_t sub = wb * (SURTR_LANES / SURTR_SB) + l / SURTR_SB;
+                ok = ok && sub < nUnd;
+                i = (ok ? und[sub] : 0u) * SURTR_SB + (l % SURTR_SB);
+            }
+            valid4[g] = ok && i < V;
             const uint32_t ii = valid4[g] ? i : 0u;
             if (sorted)
             {

@@ -65,7 +65,7 @@ struct PrepPool { char* base; size_t per_wg; uint32_t VMAX; };
 static size_t prep_bytes_per_wg(uint32_t VMAX)
 {
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_LANES + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
+    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
 }
 
 struct FragRec
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     auto take = [&](size_t bytes) { char* r = sp; sp += (bytes + 255) & ~(size_t)255; return r; };
     uint32_t* needy = (uint32_t*)take((size_t)pool.VMAX * 4);
     uint32_t* orig = (uint32_t*)take((size_t)pool.VMAX * 4);
-    uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 4);
+    uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_SB + 2) * 4);
     unsigned long long* gmask = (unsigned long long*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -1957,10 +1957,10 @@ static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const floa
                 for (int c = 0; c < 3; ++c) pos_s[3 * (size_t)(a + i) + c] = pos[3 * (size_t)(a + v) + c];
                 rad_s[a + i] = rad[a + v];
             }
-            const uint32_t nb = (m + SURTR_LANES - 1) / SURTR_LANES;
+            const uint32_t nb = (m + SURTR_SB - 1) / SURTR_SB;
             for (uint32_t blk = 0; blk < nb; ++blk)
             {
-                const uint32_t i0 = blk * SURTR_LANES, i1 = std::min(m, i0 + (uint32_t)SURTR_LANES);
+                const uint32_t i0 = blk * SURTR_SB, i1 = std::min(m, i0 + (uint32_t)SURTR_SB);
                 double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
                 for (uint32_t i = i0; i < i1; ++i) for (int c = 0; c < 3; ++c) { blo[c] = std::min(blo[c], (double)pos_s[3 * (size_t)(a + i) + c]); bhi[c] = std::max(bhi[c], (double)pos_s[3 * (size_t)(a + i) + c]); }
                 const float cx = (float)((blo[0] + bhi[0]) / 2), cy = (float)((blo[1] + bhi[1]) / 2), cz = (float)((blo[2] + bhi[2]) / 2);
