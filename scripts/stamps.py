@@ -12,7 +12,7 @@ eng = E.Engine(0)
 eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = eng.fracture_event(0, 4096, flags=flags)
-buf = (ctypes.c_ulonglong * 80)()
+buf = (ctypes.c_ulonglong * 96)()
 L.surtr_debug_stamps(buf, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
@@ -34,6 +34,7 @@ eng.close()
 
 print("prep kernel: pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[62 + i] for i in range(8)])
 print("prep kernel: per-WG lifetime avg %.3g max %.3g, work avg %.3g max %.3g cycles over %d WGs" % (buf[56] / max(buf[58], 1), buf[57], buf[59] / max(buf[58], 1), buf[60], buf[58]))
+print("park (lane-0 cycles): index_live %d, island labels %d, roots+arena %d, write %d; image load %d" % tuple(buf[80:85]))
 print("select (lane-0 cycles): loop top %d, count+scan %d, write %d" % tuple(buf[76:79]))
 print("prep kernel (lane-0 cycles): planes %d, select %d, image alloc %d, mask copy %d, emit %d, hist+header %d" % tuple(buf[70:76]))
 if flags & 2:

@@ -51,7 +51,7 @@
 // Diagnostic build only (-DSURTR_STAMP): lane 0 accumulates s_memtime deltas per phase into a
 // global table that no product code reads.
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-__device__ unsigned long long g_stamp[80];
+__device__ unsigned long long g_stamp[96];
 #ifdef SURTR_STAMP_SMALL
 #define STAMP_WHO (blockDim.x == 64 && gridDim.x > 1900)
 #else

@@ -154,15 +154,15 @@ static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX)
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
 template <uint32_t LV, uint32_t LH>
-struct LdsTopoT
+struct alignas(16) LdsTopoT
 {
+    static_assert(LV % 16 == 0 && LH % 8 == 0, "clip_image copies 16-byte words into these arrays");
     static constexpr uint32_t kLV = LV, kLH = LH;
-    uint16_t loff[LV];
-    uint8_t llen[LV];
-    uint8_t fc[LV];
-    uint2 blk[LV / SURTR_LANES + 2];
-    unsigned long long align_;
-    uint16_t ring[LH];
+    alignas(16) uint16_t loff[LV];
+    alignas(16) uint8_t llen[LV];
+    alignas(16) uint8_t fc[LV];
+    alignas(16) uint2 blk[LV / SURTR_LANES + 2];
+    alignas(16) uint16_t ring[LH];
 };
 typedef LdsTopoT<SURTR_LV, SURTR_LH> LdsTopo;          // Mesh solids: two workgroups of 256 threads per CU
 typedef LdsTopoT<2 * SURTR_LV, 2 * SURTR_LH> LdsTopoBig;   // the few Mesh solids with a large band: one workgroup per CU
@@ -269,6 +269,7 @@ __device__ static int clip_image(const char* img, uint32_t n, uint32_t hsum, con
                                  LT& L, Consume consume)
 {
     const uint32_t tid = threadIdx.x;
+    STAMP_DECL;
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
     const ImgLayout lay = img_layout(F, nbV, n, hsum);
     Topo<InLds> T = lds_topo(S, L);
@@ -279,10 +280,11 @@ __device__ static int clip_image(const char* img, uint32_t n, uint32_t hsum, con
         const uint32_t* nz = (const uint32_t*)(img + lay.nzero);
         for (uint32_t k = tid; k < F; k += group_size()) { sh.hist[k] = hs[k]; sh.zhist[k] = zs[k]; sh.nzero[k] = nz[k]; }
         if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; }
-        // sections are padded to 16 bytes and the LDS arrays to a multiple of 4 entries: copy whole words
-        auto copy_words = [&](void* dst, const void* src, uint32_t bytes) {
-            uint32_t* d = (uint32_t*)dst; const uint32_t* q = (const uint32_t*)src;
-            for (uint32_t i = tid; i < (bytes + 3u) / 4u; i += group_size()) d[i] = q[i];
+        // sections are padded to 16 bytes, the LDS arrays are 16-byte aligned multiples of 16 bytes: copy 16-byte words
+        struct alignas(16) W16 { uint32_t a, b, c, d; };
+        auto copy_words = [&](void* dst, const void* src, uint32_t bytes) {       // 16 bytes per lane and round trip
+            W16* d = (W16*)dst; const W16* q = (const W16*)src;
+            for (uint32_t i = tid; i < (bytes + 15u) / 16u; i += group_size()) d[i] = q[i];
         };
         copy_words(L.loff, img + lay.loff, 2u * n);
         copy_words(L.llen, img + lay.llen, n);
@@ -291,6 +293,7 @@ __device__ static int clip_image(const char* img, uint32_t n, uint32_t hsum, con
         copy_words(S.pos, img + lay.pos, 12u * n);
         T.nS = n; T.nLive = n; T.hUsed = hsum;
         __syncthreads();
+        STAMP(84);
         rc = clip_planes(T, F, sh, in, (const unsigned long long*)(img + lay.mask), SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
         __syncthreads();
         if (rc == 0) return consume(T);
@@ -392,7 +395,9 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
 {
     typedef typename TT::idx_t I;
     const uint32_t tid = threadIdx.x, nS = T.nS;
+    STAMP_DECL;
     const uint2 tot = index_live(T, sh);              // aux0 = packed index, aux2 = packed ring offset
+    STAMP(80);
     uint32_t* lab = T.aux1;
     for (uint32_t v = tid; v < nS; v += group_size()) lab[v] = v;
     __syncthreads();
@@ -418,11 +423,13 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
         __syncthreads();     // read before lane 0 clears it again
         if (!more) break;
     }
+    STAMP(81);
     auto rootfn = [&](uint32_t v) -> uint2 { return make_uint2((T.alive(v) && lab[v] == v) ? 1u : 0u, 0u); };
     uint32_t ni = 0, dum = 0;
     scan_blocks(nS, T.blk, sh, rootfn, ni, dum);
     uint32_t voff, hoff, ioff;
     if (!arena_take(A, sh, tot.x, tot.y, ni, voff, hoff, ioff)) return SURTR_E_CAPACITY;
+    STAMP(82);
     if (ni == 1)
     {
         write_solid(T, A.pos, A.loff, A.llen, A.nbr, voff, hoff);
@@ -484,6 +491,7 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
     }
     rec.mv_off = voff; rec.mv_n = tot.x; rec.mh_off = hoff; rec.mh_n = tot.y; rec.ni = ni; rec.isl_off = ioff;
     __syncthreads();
+    STAMP(83);
     return 0;
 }
 
@@ -2403,10 +2411,10 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
 }
 
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
-int surtr_debug_stamps(unsigned long long out[80], int reset)
+int surtr_debug_stamps(unsigned long long out[96], int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 80) != hipSuccess) return SURTR_E_HIP;
-    if (reset) { unsigned long long z[80] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 96) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[96] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp), z, sizeof(z)); }
     return SURTR_OK;
 }
 #endif
