@@ -396,6 +396,90 @@ __device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A,
     typedef typename TT::idx_t I;
     const uint32_t tid = threadIdx.x, nS = T.nS;
     STAMP_DECL;
+    // Fast path (LDS topology, one island -- the common case): the live slots as a list, labels and packed indices as
+    // 16-bit arrays in the free tail of the ring area, every pass over the live vertices only.
+    if (sizeof(I) == 2)
+    {
+        const uint32_t nA = select_count(T.fc, SURTR_NEVER, nS, sh);        // live <=> no plane clipped it
+        uint32_t wtop = T.capH;
+        auto carve = [&](uint32_t n) -> uint16_t* {
+            if (wtop < T.hUsed + n + 8u) return nullptr;
+            wtop -= n; return (uint16_t*)(void*)(T.ring + wtop);
+        };
+        uint16_t* alist = carve(nA); uint16_t* lab = carve(nS); uint16_t* pidx = carve(nS); uint16_t* roff = carve(nA + 1u);
+        if (alist && lab && pidx && roff && T.hUsed < 0xFFFFu)
+        {
+            select_write(T.fc, SURTR_NEVER, nS, sh, WArr<uint16_t>{alist, nullptr});
+            for (uint32_t i = tid; i < nA; i += group_size()) { const uint32_t v = alist[i]; lab[v] = (uint16_t)v; pidx[v] = (uint16_t)i; }
+            __syncthreads();
+            // min-label propagation with one pointer jump per round (CheckMeshIsland, Src/Surtr.cpp:2157-2201, finds the same components)
+            while (true)
+            {
+                if (tid == 0) sh.changed = 0;
+                __syncthreads();
+                bool ch = false;
+                for (uint32_t i = tid; i < nA; i += group_size())
+                {
+                    const uint32_t v = alist[i];
+                    uint32_t m = lab[v];
+                    const I* r = T.ring + T.loff[v];
+                    const uint32_t len = T.llen[v];
+                    for (uint32_t q = 0; q < len; ++q) { const uint32_t o = lab[(uint32_t)r[q]]; m = o < m ? o : m; }
+                    const uint32_t mm = lab[m];
+                    m = mm < m ? mm : m;
+                    if (m < lab[v]) { lab[v] = (uint16_t)m; ch = true; }
+                }
+                if (ch) sh.changed = 1;
+                __syncthreads();
+                const bool more = sh.changed != 0;
+                __syncthreads();
+                if (!more) break;
+            }
+            if (tid == 0) sh.changed = 0;
+            __syncthreads();
+            {
+                bool other = false;
+                const uint32_t root = lab[alist[0]];
+                for (uint32_t i = tid; i < nA; i += group_size()) if (lab[alist[i]] != root) other = true;
+                if (other) sh.changed = 1;
+            }
+            __syncthreads();
+            const bool single = sh.changed == 0;
+            __syncthreads();
+            if (single)
+            {
+                // ring offsets of the packed solid: exclusive scan of the ring lengths in list order
+                auto lenfn = [&](uint32_t i) -> uint2 { return make_uint2((uint32_t)T.llen[alist[i]], 0u); };
+                uint32_t hh = 0, dum = 0;
+                scan_blocks(nA, T.blk, sh, lenfn, hh, dum);
+                const uint32_t nbA = (nA + SURTR_LANES - 1u) >> SURTR_LSH;
+                for (uint32_t b = wave_id(); b < nbA; b += group_waves())
+                {
+                    const uint32_t i = (b << SURTR_LSH) + lane_id();
+                    uint2 c = make_uint2(0u, 0u);
+                    if (i < nA) c = lenfn(i);
+                    const uint2 e = wave_excl2(c);
+                    if (i < nA) roff[i] = (uint16_t)(T.blk[b].x + e.x);
+                }
+                uint32_t voff, hoff, ioff;
+                if (!arena_take(A, sh, nA, hh, 1u, voff, hoff, ioff)) return SURTR_E_CAPACITY;
+                for (uint32_t i = tid; i < nA; i += group_size())
+                {
+                    const uint32_t v = alist[i], id = voff + i;
+                    A.pos[3 * (size_t)id] = T.pos[3 * v]; A.pos[3 * (size_t)id + 1] = T.pos[3 * v + 1]; A.pos[3 * (size_t)id + 2] = T.pos[3 * v + 2];
+                    const uint32_t lo = hoff + roff[i], len = T.llen[v];
+                    A.loff[id] = lo; A.llen[id] = len;
+                    const I* r = T.ring + T.loff[v];
+                    for (uint32_t q = 0; q < len; ++q) A.nbr[lo + q] = (int32_t)pidx[(uint32_t)r[q]];
+                }
+                if (tid == 0) A.isl[ioff] = make_uint2(nA, hh);
+                rec.mv_off = voff; rec.mv_n = nA; rec.mh_off = hoff; rec.mh_n = hh; rec.ni = 1u; rec.isl_off = ioff;
+                __syncthreads();
+                STAMP(83);
+                return 0;
+            }
+        }
+    }
     const uint2 tot = index_live(T, sh);              // aux0 = packed index, aux2 = packed ring offset
     STAMP(80);
     uint32_t* lab = T.aux1;
