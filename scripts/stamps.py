@@ -35,6 +35,8 @@ eng.close()
 print("prep kernel: pair cost histogram (cycles < 2^17, 2^18, ...):", [buf[62 + i] for i in range(8)])
 print("prep kernel: per-WG lifetime avg %.3g max %.3g, work avg %.3g max %.3g cycles over %d WGs" % (buf[56] / max(buf[58], 1), buf[57], buf[59] / max(buf[58], 1), buf[60], buf[58]))
 print("park (lane-0 cycles): index_live %d, island labels %d, roots+arena %d, write %d; image load %d" % tuple(buf[80:85]))
+print("one-wave clips: convex kernel: prepass %d, planes %d, park %d over %d tasks; refit: prepass %d, planes %d, park %d over %d tasks" % tuple(buf[86:94]))
+print("refit: hull4 %d, k-DOP %d (lane-0 cycles)" % (buf[94], buf[95]))
 print("select (lane-0 cycles): loop top %d, count+scan %d, write %d" % tuple(buf[76:79]))
 print("prep kernel (lane-0 cycles): planes %d, select %d, image alloc %d, mask copy %d, emit %d, hist+header %d" % tuple(buf[70:76]))
 if flags & 2:

@@ -249,13 +249,32 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
             bmask = (unsigned long long*)bblk - nbV;
             capEmit = LT::kLH - nbV * 8u;
         }
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
         rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
         if (rc == 0)
         {
             __syncthreads();
             rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
         }
         __syncthreads();
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long q2 = __builtin_readcyclecounter();
+        if (rc == 0)
+        {
+            const int r2 = consume(T);
+            if (threadIdx.x == 0 && blockDim.x == 64)
+            {
+                const int o = gridDim.x > 1900 && F > 8 ? 86 : 90;      // 86..89 convex kernel, 90..93 refit
+                atomicAdd(&g_stamp[o], q1 - q0); atomicAdd(&g_stamp[o + 1], q2 - q1); atomicAdd(&g_stamp[o + 2], __builtin_readcyclecounter() - q2); atomicAdd(&g_stamp[o + 3], 1ull);
+            }
+            return r2;
+        }
+#endif
         if (rc == 0) return consume(T);
     }
     if (rc != SURTR_OVERFLOW) return rc;
@@ -855,9 +874,10 @@ __global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restri
                                                          uint32_t n_pieces, uint32_t cell_begin, Arena A,
                                                          uint2* __restrict__ blk, FragRec* __restrict__ frags,
                                                          uint32_t cap_frags, surtr_counts* __restrict__ counts,
-                                                         const uint2* __restrict__ pair_list)
+                                                         const uint2* __restrict__ pair_list, uint32_t* __restrict__ forder)
 {
     __shared__ Shared sh;
+    for (uint32_t q = threadIdx.x; q < 16u; q += group_size()) sh.hist[q] = 0;
     auto fn = [&](uint32_t p) -> uint2 { return make_uint2(pairs[p].ni, 0u); };
     uint32_t nf = 0, dum = 0;
     scan_blocks(n_pairs, blk, sh, fn, nf, dum);
@@ -885,17 +905,34 @@ __global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restri
                     fr.cv_off = r.cv_off; fr.cv_n = r.cv_n; fr.ch_off = r.ch_off; fr.ch_n = r.ch_n;
                     fr.idx_off = 0; fr.idx_n = 0; fr.o_mv = fr.o_mh = fr.o_cv = fr.o_ch = fr.o_idx = 0;
                     frags[f] = fr;
+                    // size class (log2 of the vertex count): k_refit / k_faces start with the large fragments
+                    uint32_t cls = 0; while ((is.x >> (cls + 1u)) != 0u && cls < 15u) ++cls;
+                    forder[(size_t)cls * cap_frags + atomicAdd(&sh.hist[cls], 1u)] = f;      // (one workgroup: LDS counters)
                     vo += is.x; ho += is.y;
                 }
             }
         }
     }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < 16u; q += group_size()) A.cursors[32u + q] = sh.hist[q];
     if (threadIdx.x == 0)
     {
         counts->n_frag = nf <= cap_frags ? nf : 0u;
         counts->n_pairs = n_pairs;
         if (nf > cap_frags) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY);
     }
+}
+
+// next ticket of a per-fragment kernel -> fragment, large size classes first (k_frag_table filled forder)
+__device__ static uint32_t frag_of_ticket(const Arena& A, const uint32_t* __restrict__ forder, uint32_t cap_frags, uint32_t t)
+{
+    for (int cls = 15; cls >= 0; --cls)
+    {
+        const uint32_t cnt = A.cursors[32 + cls];
+        if (t < cnt) return forder[(size_t)cls * cap_frags + t];
+        t -= cnt;
+    }
+    return 0xFFFFFFFFu;
 }
 
 // ------------------------------------------------------------------ k_refit
@@ -937,7 +974,7 @@ __device__ __forceinline__ float hull_vol(const float* a, const float* b, const 
 }
 
 __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
-                                                    ScratchPool pool, Arena A)
+                                                    ScratchPool pool, Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags)
 {
     __shared__ Shared sh;
     __shared__ ArgF slotF[SURTR_NWAVE];
@@ -951,13 +988,16 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
     while (true)
     {
         __syncthreads();
-        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[6], 1u);
+        if (tid == 0) sh.misc[7] = frag_of_ticket(A, forder, cap_frags, atomicAdd(&A.cursors[6], 1u));
         __syncthreads();
         const uint32_t f = sh.misc[7];
         if (f >= nf) break;
         FragRec fr = frags[f];
         const float* mp = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t n = fr.mv_n;
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long r0 = __builtin_readcyclecounter();
+#endif
         // ---- BuildFirstHull (Src/VMACH.cpp:1036-1085) with limit min(n,4) = 4 ----
         ArgF a; a.i = 0xFFFFFFFFu; a.v = 0.f;
         for (uint32_t v = tid; v < n; v += group_size())
@@ -1020,6 +1060,9 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        const unsigned long long r1 = __builtin_readcyclecounter();
+#endif
         // ---- Kdop::Calc(Polyhedron) (Src/Kdop.cpp:92-115): first minimum / first maximum of n.v ----
         for (int k = 0; k < 4; ++k)
         {
@@ -1042,6 +1085,9 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
+#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+        if (tid == 0) { const unsigned long long r2 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[94], r1 - r0); atomicAdd(&g_stamp[95], r2 - r1); }
+#endif
         SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
@@ -1236,7 +1282,7 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
 
 __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
-                                                    Arena A)
+                                                    Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags)
 {
     __shared__ Shared sh;
     // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
@@ -1255,7 +1301,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
     while (true)
     {
         __syncthreads();
-        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[7], 1u);
+        if (tid == 0) sh.misc[7] = frag_of_ticket(A, forder, cap_frags, atomicAdd(&A.cursors[7], 1u));
         __syncthreads();
         const uint32_t f = sh.misc[7];
         if (f >= nf) break;
@@ -1725,6 +1771,7 @@ struct surtr_ctx
     PrepPool prep{nullptr, 0, 0}; uint32_t n_wg_prep = 0;
     ImgArena img{nullptr, 0};
     uint32_t* d_order = nullptr; uint32_t cap_order = 0;
+    uint32_t* d_forder = nullptr;    // fragments by size class, 16 x cap_frags
     uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
 #ifndef SURTR_EMUL
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
@@ -1859,7 +1906,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
-    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order);
+    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
 #ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
@@ -2249,6 +2296,8 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
         HIPCHK(hipMalloc((void**)&ctx->arena.idx, ai * 4));
         HIPCHK(hipMalloc((void**)&ctx->arena.isl, (size_t)capIsl * 8));
         HIPCHK(hipMalloc((void**)&ctx->d_frags, (size_t)capIsl * sizeof(FragRec)));
+        free_dev(ctx->d_forder); ctx->d_forder = nullptr;
+        HIPCHK(hipMalloc((void**)&ctx->d_forder, (size_t)capIsl * 16 * 4));
         ctx->arena.capV = (uint32_t)av; ctx->arena.capH = (uint32_t)ah; ctx->arena.capI = (uint32_t)ai; ctx->arena.capIsl = capIsl;
         ctx->cap_frags = capIsl;
     }
@@ -2331,7 +2380,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
 #endif
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
-                       ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list);
+                       ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list, ctx->d_forder);
     PROF_END(1);
     // refit (Convex) and faces (Mesh) of the fragments are independent: side by side on the two streams
     const bool both = (flags & SURTR_EVT_REFIT) && (flags & SURTR_EVT_RENDER);
@@ -2347,14 +2396,14 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (flags & SURTR_EVT_REFIT)
     {
         PROF_BEGIN_ON(2, st_refit);
-        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
+        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
         PROF_END_ON(2, st_refit);
     }
     if (flags & SURTR_EVT_RENDER)
     {
         PROF_BEGIN(3);
         hipLaunchKernelGGL(k_faces, dim3(std::max(n_wg, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
-                           ctx->blk_per_wg, ctx->arena);
+                           ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags);
         PROF_END(3);
     }
 #ifndef SURTR_EMUL
@@ -2442,7 +2491,7 @@ int surtr_event_refit(surtr_ctx* ctx)
     // k_refit pulls fragments from work queue 6
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 6, 0, 4, st));
     PROF_BEGIN(2);
-    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena);
+    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
     PROF_END(2);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
