@@ -179,7 +179,7 @@ struct LdsWorkT
 {
     static constexpr uint32_t kN = N;
     float pos[3 * N];
-    uint32_t succ[N], pred[N], pcnt[N], aux0[N], aux1[N], aux2[N], aux3[N];
+    uint32_t aux0[N], aux1[N], aux2[N];      // the lists every solid uses; the rarely used ones stay in global scratch
     int8_t gcomp[N];
 };
 typedef LdsWorkT<LdsTopoSmall::kLV> LdsWorkSmall;
@@ -204,8 +204,7 @@ __device__ static Topo<InLds> lds_topo(Scratch& S, LT& L, LW* W, uint32_t nv_in)
     {
         if (W != nullptr && nv_in <= LW::kN)
         {
-            T.pos = W->pos; T.succ = W->succ; T.pred = W->pred; T.pcnt = W->pcnt;
-            T.aux0 = W->aux0; T.aux1 = W->aux1; T.aux2 = W->aux2; T.aux3 = W->aux3; T.gcomp = W->gcomp;
+            T.pos = W->pos; T.aux0 = W->aux0; T.aux1 = W->aux1; T.aux2 = W->aux2; T.gcomp = W->gcomp;
             if (T.capV > LW::kN) T.capV = LW::kN;
         }
     }
