@@ -2264,8 +2264,9 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
     const uint64_t lds = (uint64_t)SURTR_LV * 16 + (uint64_t)SURTR_LH * 2;
     const uint64_t per_pair = std::min(full, lds) + ctx->vmax / 8 + 2048;
     uint64_t bytes = std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_pairs * per_pair, 1ull << 20), 4ull << 30);
+    if (const char* e = getenv("SURTR_IMG_BYTES")) { const long long v = atoll(e); if (v >= 4096) bytes = (uint64_t)v; }      // tests: a small arena
     const uint32_t cap16 = (uint32_t)(bytes / 16);
-    if (!(ctx->img.base && ctx->img.cap16 >= cap16))
+    if (!(ctx->img.base && ctx->img.cap16 >= cap16) || (getenv("SURTR_IMG_BYTES") && ctx->img.cap16 != cap16))
     {
         free_dev(ctx->img.base); ctx->img.base = nullptr;
         HIPCHK(hipMalloc((void**)&ctx->img.base, (size_t)cap16 * 16));

@@ -238,3 +238,12 @@ def test_prepare_fracture_end_to_end(emul_engine, oracle):
     meshes, convexes = scenes.fragments_as_pieces(got)
     assert len(meshes) == c.n_frag == len(convexes)
     eng.close()
+
+
+def test_image_arena_exhaustion_falls_back(emul_engine, oracle, monkeypatch):
+    """k_prep_pairs leaves the pairs it has no image room for to k_clip_pairs' own pre-pass: same result."""
+    monkeypatch.setenv("SURTR_IMG_BYTES", "16384")
+    sc = scenes.make_scene(*meshgen.bumpy_torus(40, 24), 24)
+    c, got, ref = run_event(emul_engine, oracle, sc)
+    assert c.status == 0 and c.n_frag > 10
+    assert_event_equal(got, ref)
