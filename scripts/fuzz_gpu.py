@@ -1,6 +1,7 @@
 """GPU-vs-oracle fuzz: random meshes, seeds, cell counts and piece sets; full-array comparison.
 Usage: python scripts/fuzz_gpu.py [n_cases] [seed]"""
-import os, sys, time
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
@@ -29,7 +30,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1234)
     eng = E.Engine(0)
-    bad = 0
+    bad = 0; undefined = 0
     t0 = time.time()
     for case in range(n):
         sc, kind = random_scene(rng)
@@ -42,9 +43,30 @@ def main():
         # the reference places patterns both over the AABB and around an impact point
         scale = sc["scale"] * np.float32(rng.uniform(0.6, 2.2)); shift = sc["translate"] + (rng.uniform(-0.3, 0.3, 3) * sc["scale"]).astype(np.float32)
         eng.place_cells(scale, shift)
-        c = eng.fracture_event(0, sc["n_cells"], flags=flags)
-        got = eng.download()
         planes = O.place_cells(sc["v012"], scale, shift)
+        try:
+            c = eng.fracture_event(0, sc["n_cells"], flags=flags)
+        except E.SurtrError as err:
+            # the engine refuses the input (e.g. a degenerate ACH of a box whose slabs coincide with its faces): the reference
+            # is only defined where its own walk does not leave the solid -- the oracle, run in a child process, must fail too
+            os.makedirs("gpurun_out", exist_ok=True)
+            path = "gpurun_out/fuzz_err_%d.npz" % case
+            np.savez_compressed(path, mesh_pos=sc["mesh"]["pos"], mesh_off=sc["mesh"]["off"], mesh_nbr=sc["mesh"]["nbr"],
+                                conv_pos=sc["convex"]["pos"], conv_off=sc["convex"]["off"], conv_nbr=sc["convex"]["nbr"], face_off=sc["face_off"], planes=planes, flags=flags)
+            code = ("import sys, numpy as np; sys.path.insert(0, %r); from oracle import oracle as O; d = np.load(%r); "
+                    "O.event([dict(pos=d['mesh_pos'], off=d['mesh_off'], nbr=d['mesh_nbr'])], [dict(pos=d['conv_pos'], off=d['conv_off'], nbr=d['conv_nbr'])], "
+                    "d['face_off'], d['planes'], refit=bool(int(d['flags']) & 1), render=bool(int(d['flags']) & 2), threads=1)") % (ROOT, path)
+            rc = subprocess.call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            if rc == 0:
+                bad += 1
+                print("  FAIL case", case, "engine error", err, "but the oracle succeeds", flush=True)
+            else:
+                undefined += 1
+                os.remove(path)
+                print("case %d kind %d V %d cells %d ach %d flags %d: refused by the engine (%s) and undefined for the reference (oracle exit %d)" % (
+                    case, kind, sc["mesh"]["pos"].shape[0], sc["n_cells"], use_ach, flags, err, rc), flush=True)
+            continue
+        got = eng.download()
         ref = O.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=bool(flags & 1), render=bool(flags & 2), threads=8)
         try:
             assert c.status == 0
@@ -57,7 +79,7 @@ def main():
                                 conv_pos=sc["convex"]["pos"], conv_off=sc["convex"]["off"], conv_nbr=sc["convex"]["nbr"], face_off=sc["face_off"], planes=planes, flags=flags)
             print("  FAIL case", case, str(e)[:200], flush=True)
         print("case %d kind %d V %d cells %d ach %d flags %d frags %d verts %d idx %d %s  (%.0fs)" % (case, kind, sc["mesh"]["pos"].shape[0], sc["n_cells"], use_ach, flags, c.n_frag, c.mesh_verts, c.n_idx, "ok" if ok else "MISMATCH", time.time() - t0), flush=True)
-    print("FUZZ DONE: %d cases, %d mismatches" % (n, bad))
+    print("FUZZ DONE: %d cases, %d mismatches, %d inputs outside the reference's domain" % (n, bad, undefined))
     eng.close()
     sys.exit(1 if bad else 0)
 
