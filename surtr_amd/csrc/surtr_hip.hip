@@ -624,6 +624,9 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         PairRec rec;
         memset(&rec, 0, sizeof(rec));
+#if defined(SURTR_STAMP_SMALL) && !defined(SURTR_EMUL)
+        if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
+#endif
         bool skip = outside != nullptr && outside[piece] != 0;
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
@@ -643,6 +646,9 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
+#if defined(SURTR_STAMP_SMALL) && !defined(SURTR_EMUL)
+        if (tid == 0) for (int q = 0; q < 16; ++q) if (sh.ph[q]) atomicAdd(&g_stamp[q], sh.ph[q]);
+#endif
     }
 }
 

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def product_library():
+    """The host helpers of the C ABI (Voronoi cells, neighbour rings, ...) live in libsurtr_hip.so: build it when a fresh
+    checkout has none (hipcc cross-compiles gfx950 without a GPU).  Building is not a fallback: nothing is computed here."""
+    from surtr_amd import engine
+    if not os.path.exists(engine.lib_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O
