@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from surtr_amd import engine as E, scenes as S
 sc = S.torus_scene(4096)
+if os.environ.get("SURTR_ACH"):
+    _e = E.Engine(0); sc["convex"], _ = S.ach_convex(_e, sc["mesh"]["pos"]); _e.close()
 for lib in sys.argv[1:]:
     E._use_library_for_tests(os.path.abspath(lib))
     eng = E.Engine(0)

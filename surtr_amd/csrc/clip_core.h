@@ -723,7 +723,7 @@ __device__ inline void prepass_finish_hist(const uint32_t F, Shared& sh)
 }
 
 template <class TT>
-__device__ void prepass_emit(const SolidIn in, const uint32_t F, Shared& sh, Topo<TT>& T, const unsigned long long* bmask,
+__device__ __attribute__((always_inline)) inline void prepass_emit(const SolidIn in, const uint32_t F, Shared& sh, Topo<TT>& T, const unsigned long long* bmask,
                              const uint2* bblk, uint32_t* orig, const uint32_t n, const uint32_t hsum)
 {
     typedef typename TT::idx_t I;
@@ -793,7 +793,7 @@ __device__ void prepass_emit(const SolidIn in, const uint32_t F, Shared& sh, Top
 // capH_emit: ring entries available while the masks are still in use.
 // Returns 0 or SURTR_OVERFLOW (does not fit T) -- uniform over the workgroup.
 template <class TT>
-__device__ int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh, unsigned long long* bmask, uint2* bblk,
+__device__ __attribute__((always_inline)) inline int prepass(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh, unsigned long long* bmask, uint2* bblk,
                        uint32_t capH_emit, unsigned long long* spill_mask, uint2* spill_blk)
 {
     const uint32_t tid = threadIdx.x;
@@ -943,8 +943,10 @@ __device__ void squeeze(Topo<TT>& T, Shared& sh, const SqueezeTmp tmp)
 // ---------------------------------------------------------------------------
 // The plane loop on a reduced solid.  `in`/`bmask` are only consulted in the all-in-plane corner case.
 // Returns 0 (T.nLive == 0: empty), an error code, or SURTR_OVERFLOW.
-template <class TT>
-__device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const SolidIn in, const unsigned long long* bmask,
+// (always inlined: as a call the Topo would live in private memory and every field access would be a scratch load)
+// MULTIWAVE: compiled for a workgroup of several waves (a variant of the edge-cut sweep that pays off there only).
+template <class TT, bool MULTIWAVE = true>
+__device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const SolidIn in, const unsigned long long* bmask,
                            const SqueezeTmp tmp)
 {
     typedef typename TT::idx_t I;
@@ -1002,7 +1004,8 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         STAMP(77);
         // the clipped vertices, ascending, and their kept-neighbour counts (the ring is not growing yet: floor = hUsed)
         WArr<uint16_t> clist = carve16(nC, T.hUsed, T.aux3);
-        WArr<uint8_t> cutcnt = carve8(nC, T.hUsed, T.aux2);
+        WArr<uint16_t> cutcnt = carve16(nC, T.hUsed, T.aux2);      // per clipped vertex: bit j = ring slot j holds a kept neighbour (rings of
+                                                                   // 16 and more entries: 0x8000 | their number)
         if (nC) select_write(sel_arr, sel_val, nS, sh, clist); else __syncthreads();
         STAMP(78);
         if (T.zmode)
@@ -1075,7 +1078,7 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
         // ---- new vertices on straddling edges, in (vertex, slot) order (:333-357) ----
         auto cutfn = [&](uint32_t i) -> uint2 {
             const uint32_t v = clist.get(i);
-            uint32_t c = 0;
+            uint32_t c = 0, mask = 0;
             const I* r = T.ring + T.loff[v];
             const uint32_t deg = T.llen[v];
             for (uint32_t j0 = 0; j0 < deg; j0 += 4)
@@ -1087,9 +1090,9 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cu[q] = T.cmp(u[q] < TT::SENT ? u[q] : 0u);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (j0 + q < deg && u[q] < TT::SENT && cu[q] > 0) ++c;
+                for (int q = 0; q < 4; ++q) if (j0 + q < deg && u[q] < TT::SENT && cu[q] > 0) { ++c; if (j0 + q < 15u) mask |= 1u << (j0 + q); }
             }
-            cutcnt.set(i, c);
+            cutcnt.set(i, deg < 16u ? mask : (0x8000u | c));
             return make_uint2(c, 1u);
         };
         // every wave counts a contiguous range of 64-vertex blocks of the clipped list: one barrier gives M and, in the
@@ -1151,7 +1154,8 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
             {
                 const uint32_t i = (b << SURTR_LSH) + l;
                 uint2 c = make_uint2(0u, 0u);
-                if (i < nC) c.x = cutcnt.get(i);
+                uint32_t km = 0;
+                if (i < nC) { km = cutcnt.get(i); c.x = (km & 0x8000u) ? (km & 0x7FFFu) : (uint32_t)__builtin_popcount(km); }
                 const uint2 s2 = wave_incl_scan2(c);
                 const uint32_t base = run;
 #ifdef SURTR_EMUL
@@ -1163,6 +1167,21 @@ __device__ int clip_planes(Topo<TT>& T, const uint32_t F, Shared& sh, const Soli
                 {
                     const uint32_t v = clist.get(i);
                     uint32_t t = base + s2.x - c.x;
+                    if (MULTIWAVE && !(km & 0x8000u))
+                    {
+                        // the count left the kept slots as a bit mask: no ring is read unless two of them could hold the same vertex
+                        if (c.x >= 2u)
+                        {
+                            const I* r2 = T.ring + T.loff[v];
+                            for (uint32_t mm = km; mm; mm &= mm - 1u)
+                            {
+                                const uint32_t ja = (uint32_t)__builtin_ctz(mm), ua = r2[ja];
+                                for (uint32_t lo = km & ((1u << ja) - 1u); lo; lo &= lo - 1u) if ((uint32_t)r2[__builtin_ctz(lo)] == ua) dup = true;
+                            }
+                        }
+                        for (uint32_t mm = km; mm; mm &= mm - 1u) { srcv.set(t, v); srcj.set(t, (uint32_t)__builtin_ctz(mm)); ++t; }
+                        continue;
+                    }
                     const I* r = T.ring + T.loff[v];
                     const uint32_t deg = T.llen[v];
                     for (uint32_t j0 = 0; j0 < deg; j0 += 4)

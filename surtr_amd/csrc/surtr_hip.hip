@@ -258,7 +258,7 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
         if (rc == 0)
         {
             __syncthreads();
-            rc = clip_planes(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
+            rc = clip_planes<InLds, LW::kN == 0>(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
         }
         __syncthreads();
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
