@@ -664,7 +664,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #endif
 #define SURTR_PREP_NB 1024u         // 64-vertex blocks whose masks fit this kernel's LDS (65536 vertices)
 #ifndef SURTR_PREP_WAVES
-#define SURTR_PREP_WAVES 6
+#define SURTR_PREP_WAVES 7       // workgroups per CU = waves per SIMD: the register budget is set for that (<= 72 VGPRs)
 #endif
 __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         uint2* bblk = nbV <= SURTR_PREP_NB ? lblk : gblk;
         uint32_t n = 0, hsum = 0;
 #ifndef SURTR_PREP_G
-#define SURTR_PREP_G 2
+#define SURTR_PREP_G 1           // occupancy hides the gather latency here, not unrolling
 #define SURTR_PREP_NBATCH 4
 #endif
         prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
@@ -1772,7 +1772,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
 struct surtr_ctx
 {
     int device = 0;
-    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1536;
+    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792;
     PrepPool prep{nullptr, 0, 0}; uint32_t n_wg_prep = 0;
     ImgArena img{nullptr, 0};
     uint32_t* d_order = nullptr; uint32_t cap_order = 0;
@@ -1883,7 +1883,7 @@ int surtr_create(int device, surtr_ctx** out)
             uint32_t small_per_cu = 8u;
             if (const char* e = getenv("SURTR_SMALL_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) small_per_cu = (uint32_t)v; }
             ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * small_per_cu;
-            uint32_t prep_per_cu = 6u;
+            uint32_t prep_per_cu = SURTR_PREP_WAVES;
             if (const char* e = getenv("SURTR_PREP_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) prep_per_cu = (uint32_t)v; }
             ctx->max_wg_prep = (uint32_t)prop.multiProcessorCount * prep_per_cu;
         }
