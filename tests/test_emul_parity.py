@@ -1,5 +1,7 @@
 """CPU tier: the product kernels compiled as a single-lane emulation (tests/emul) against the oracle.
 This checks kernel *logic* (ordering rules, in-plane fallback, band reduction); races need the GPU tier."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -247,3 +249,22 @@ def test_image_arena_exhaustion_falls_back(emul_engine, oracle, monkeypatch):
     c, got, ref = run_event(emul_engine, oracle, sc)
     assert c.status == 0 and c.n_frag > 10
     assert_event_equal(got, ref)
+
+
+def test_degenerate_ach_of_a_box_is_refused(emul_engine):
+    """Found by scripts/fuzz_gpu.py: the ACH of an axis-aligned box has slabs that coincide with the box faces up to
+    rounding and near-duplicate vertices; a cell plane then leaves a clipped vertex linked from a surviving one, where the
+    reference indexes with ID = -1 (Src/Poly.cpp:464-495).  The engine must answer SURTR_E_TOPOLOGY, not crash."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degenerate_ach_cube.npz"))
+    eng = emul_engine.Engine(0)
+    eng.upload_pieces([{"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}],
+                      [{"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}])
+    eng.upload_planes(np.uint32([0, d["planes"].shape[0]]), d["planes"])
+    with pytest.raises(emul_engine.SurtrError) as e:
+        eng.fracture_event(0, 1, flags=3)
+    assert e.value.code == emul_engine.E_TOPOLOGY
+    # the context stays usable
+    sc = scenes.cube_scene(8)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+    assert eng.fracture_event(0, 8).n_frag == 8
+    eng.close()
