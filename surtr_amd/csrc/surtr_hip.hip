@@ -606,7 +606,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                                                     const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                     uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                     ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
-                                                    const uint2* __restrict__ pair_list)
+                                                    const uint2* __restrict__ pair_list, uint32_t* __restrict__ porder)
 {
     __shared__ Shared sh;
     __shared__ LdsTopoSmall L;
@@ -646,6 +646,40 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
+        if (rec.cv_n != 0 && porder != nullptr)
+        {
+            // Cost class of the Mesh pre-pass of this pair, so that k_prep_pairs can start with the expensive ones: the
+            // sphere test of its pass A0 on every eighth group of the piece's sorted vertices (sh.planes / sh.pmar still
+            // hold this cell's planes and margins).  An estimate only: it orders work, it decides nothing.
+            const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
+            const float4* bs = P.mbsph + P.mbo[piece];
+            const uint32_t nsb = (V + SURTR_SB - 1u) / SURTR_SB;
+            uint32_t und = 0;
+            for (uint32_t sb = tid * 8u; sb < nsb; sb += group_size() * 8u)
+            {
+                const float4 sp = bs[sb];
+                const float mag = fabsf(sp.x) + fabsf(sp.y) + fabsf(sp.z) + sp.w;
+                bool decided = false;
+                for (uint32_t k = 0; k < F; ++k)
+                {
+                    const float4 mk = sh.pmar[k];
+                    const float sk = plane_dist(sh.planes[k], sp.x, sp.y, sp.z);
+                    const float margin = sp.w * mk.x + mk.y + mk.z * mag;
+                    if (sk > margin) { decided = true; break; }
+                    if (!(sk < -margin)) break;
+                }
+                if (!decided) ++und;
+            }
+            const uint2 tot = wave_incl_scan2(make_uint2(und, 0u));
+            if (tid == group_size() - 1u)
+            {
+                // half-octave classes of the sampled count (1 .. ~V/64)
+                uint32_t l2 = 0; while ((tot.x >> (l2 + 1u)) != 0u) ++l2;
+                uint32_t cls = 2u * l2 + (l2 ? ((tot.x >> (l2 - 1u)) & 1u) : 0u);
+                cls = cls > 4u ? cls - 4u : 0u; if (cls > 15u) cls = 15u;
+                porder[(size_t)cls * n_pairs + atomicAdd(&A.cursors[48u + cls], 1u)] = p;
+            }
+        }
 #if defined(SURTR_STAMP_SMALL) && !defined(SURTR_EMUL)
         if (tid == 0) for (int q = 0; q < 16; ++q) if (sh.ph[q]) atomicAdd(&g_stamp[q], sh.ph[q]);
 #endif
@@ -670,7 +704,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
-                                                         uint32_t* __restrict__ order)
+                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
@@ -693,7 +727,18 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     while (true)
     {
         __syncthreads();
-        if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[9], 1u);
+        if (tid == 0)
+        {
+            // next ticket -> pair, expensive cost classes first (k_clip_convex filled porder with the pairs whose Convex survived)
+            uint32_t t = atomicAdd(&A.cursors[9], 1u), pp = 0xFFFFFFFFu;
+            for (int cls = 15; cls >= 0; --cls)
+            {
+                const uint32_t cnt = A.cursors[48 + cls];
+                if (t < cnt) { pp = porder[(size_t)cls * n_pairs + t]; break; }
+                t -= cnt;
+            }
+            sh.misc[7] = pp;
+        }
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
@@ -2263,7 +2308,7 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
     if (ctx->cap_order < n_pairs)
     {
         free_dev(ctx->d_order); ctx->d_order = nullptr;
-        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 16 * 4));
+        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 32 * 4));      // two tables: clip order, pre-pass order
         ctx->cap_order = n_pairs;
     }
     const uint64_t full = (uint64_t)ctx->vmax * 16 + (uint64_t)ctx->hmax * 2;
@@ -2354,12 +2399,12 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_BEGIN(6);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list);
+                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order);
     PROF_END(6);
     PROF_BEGIN(7);
     if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), ctx->d_pairs, d_pair_list, ctx->d_order);
+                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) fills the CUs two by two; both run side by side.
