@@ -809,7 +809,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             uint32_t cls = 15u;
             if (fmt == IMG_NONE) cls = 13u;
             else if (fmt == IMG_NARROW)
-                cls = (n + capV / 5u > capV || hsum + SURTR_LH / 6u > SURTR_LH) ? 14u : 1u + (n >> 9 < 12u ? n >> 9 : 12u);
+                cls = (n + capV / 5u > capV || hsum + SURTR_LH / 6u > SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
             if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
