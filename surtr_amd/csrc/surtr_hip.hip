@@ -1,6 +1,7 @@
 // surtr_hip.hip -- kernels of the fracture event + the C ABI of include/surtr_hip.h.
 //
-// Event pipeline (all on the caller's HIP stream, inputs resident in HBM):
+// Event pipeline (on the caller's HIP stream plus one internal stream for the kernels that may overlap -- k_clip_pairs beside
+// k_clip_pairs_big, k_refit beside k_faces -- fenced by events; inputs resident in HBM):
 //   k_place_cells   A3   Polygon3D::Scale/Translate + ConstructFacePlane      (Src/VMACH.cpp:302-310, 506-534)
 //   k_clip_convex   A7   Convex of every (cell, piece) pair, one wave per task (Src/Surtr.cpp:1466-1468)
 //   k_prep_pairs    A7   pre-pass of the Mesh of every pair whose Convex survived: the vertices the planes can touch,
