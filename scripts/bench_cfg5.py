@@ -3,6 +3,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from surtr_amd import engine as E, scenes as S, meshgen as G
+if os.environ.get('SURTR_LIB'):
+    E._use_library_for_tests(os.path.abspath(os.environ['SURTR_LIB']))
 sc = S.make_scene(*G.bumpy_torus(), 256)
 eng = E.Engine(0)
 eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])

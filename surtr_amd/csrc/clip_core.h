@@ -91,7 +91,7 @@ __device__ unsigned long long g_stamp[96];
 #ifdef SURTR_EMUL
 #define SURTR_KEEPALL_V 12u     // (emulation: small, so that the tests still run the culling on small meshes)
 #else
-#define SURTR_KEEPALL_V 256u    // solids up to this many vertices skip the pre-pass culling
+#define SURTR_KEEPALL_V 1536u   // solids up to this many vertices skip the pre-pass culling (they fit the LDS topology whole)
 #endif
 #endif
 #define SURTR_NEVER 0xFFu       // fc of a vertex no plane clips

@@ -695,7 +695,9 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifdef SURTR_EMUL
 #define SURTR_PREP_MINV 48u
 #else
-#define SURTR_PREP_MINV 1024u
+#ifndef SURTR_PREP_MINV
+#define SURTR_PREP_MINV 2048u      // smaller meshes are pre-passed by k_clip_pairs itself (measured on BASELINE configs[4])
+#endif
 #endif
 #define SURTR_PREP_NB 1024u         // 64-vertex blocks whose masks fit this kernel's LDS (65536 vertices)
 #ifndef SURTR_PREP_WAVES
