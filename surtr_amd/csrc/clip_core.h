@@ -886,6 +886,47 @@ __device__ inline void select_write(const uint8_t* arr, uint32_t val, uint32_t n
     __syncthreads();
 }
 
+// A small solid goes into T whole, without the pre-pass machinery (what prepass() does for a kept-whole solid, minus its
+// masks, scans and lists): rings are contiguous per solid, so the ring offset of v is in.loff[v] - in.loff[0].
+// Returns 0 or SURTR_OVERFLOW (does not fit T) -- uniform over the workgroup.
+template <class TT>
+__device__ __attribute__((always_inline)) inline int load_whole(const SolidIn in, const uint32_t F, Topo<TT>& T, Shared& sh)
+{
+    typedef typename TT::idx_t I;
+    const uint32_t tid = threadIdx.x, V = in.nv;
+    for (uint32_t k = tid; k <= SURTR_MAXF; k += group_size()) { sh.hist[k] = 0; sh.zhist[k] = 0; sh.nzero[k] = 0; }
+    if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; }
+    __syncthreads();
+    if (V == 0) { T.nS = T.nLive = T.hUsed = 0; return 0; }
+    const uint32_t base = in.loff[0], H = in.loff[V - 1u] + in.llen[V - 1u] - base;
+    if (V > T.capV || H > T.capH || V >= TT::SENT) return SURTR_OVERFLOW;
+    bool toolong = false;
+    for (uint32_t v = tid; v < V; v += group_size())
+    {
+        const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+        T.pos[3 * v] = px; T.pos[3 * v + 1] = py; T.pos[3 * v + 2] = pz;
+        const uint32_t lo = in.loff[v] - base, deg = in.llen[v];
+        if (deg > TT::MAXLEN / 2u) toolong = true;
+        T.loff[v] = (typename TT::off_t)lo; T.llen[v] = (typename TT::len_t)deg;
+        const int32_t* r = in.nbr + in.loff[v];
+        I* d = T.ring + lo;
+        for (uint32_t j = 0; j < deg; ++j) d[j] = (I)r[j];
+        uint32_t f = SURTR_NEVER;
+        for (uint32_t k = 0; k < F; ++k)
+        {
+            const int c = side_of(plane_dist(sh.planes[k], px, py, pz));
+            if (c < 0) { f = k; break; }
+            if (c == 0) atomicAdd(&sh.nzero[k], 1u);
+        }
+        T.fc[v] = (uint8_t)f;
+    }
+    if (toolong) sh.flagBad = 1;
+    __syncthreads();
+    if (sh.flagBad != 0) return SURTR_OVERFLOW;
+    T.nS = V; T.nLive = V; T.hUsed = H;
+    return 0;
+}
+
 // Global scratch used to squeeze tombstones out of a Topo (any variant) without in-place hazards.
 struct SqueezeTmp
 {
@@ -1578,7 +1619,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
 // Assigns the final (compacted) index of every live slot: idmap = T.aux0, ring offset in the packed
 // ring array = T.aux2.  Returns (vertices, ring entries).
 template <class TT>
-__device__ uint2 index_live(Topo<TT>& T, Shared& sh)
+__device__ __attribute__((always_inline)) inline uint2 index_live(Topo<TT>& T, Shared& sh)
 {
     auto livefn = [&](uint32_t v) -> uint2 {
         return T.alive(v) ? make_uint2(1u, (uint32_t)T.llen[v]) : make_uint2(0u, 0u);
@@ -1600,7 +1641,7 @@ __device__ uint2 index_live(Topo<TT>& T, Shared& sh)
 
 // Writes the live part of T as a packed solid: positions, absolute ring offsets (hoff + ...), lengths, rings.
 template <class TT>
-__device__ void write_solid(const Topo<TT>& T, float* dpos, uint32_t* dloff, uint32_t* dllen, int32_t* dnbr, uint32_t voff,
+__device__ __attribute__((always_inline)) inline void write_solid(const Topo<TT>& T, float* dpos, uint32_t* dloff, uint32_t* dllen, int32_t* dnbr, uint32_t voff,
                             uint32_t hoff)
 {
     for (uint32_t v = threadIdx.x; v < T.nS; v += group_size())

@@ -187,7 +187,7 @@ typedef LdsWorkT<LdsTopoSmall::kLV> LdsWorkSmall;
 struct NoLdsWork { static constexpr uint32_t kN = 0; };
 
 template <class LT>
-__device__ static Topo<InLds> lds_topo(Scratch& S, LT& L)
+__device__ __attribute__((always_inline)) static inline Topo<InLds> lds_topo(Scratch& S, LT& L)
 {
     Topo<InLds> T;
     T.loff = L.loff; T.llen = L.llen; T.fc = L.fc; T.gcomp = S.g_gcomp; T.ring = L.ring; T.pos = S.pos;
@@ -196,18 +196,17 @@ __device__ static Topo<InLds> lds_topo(Scratch& S, LT& L)
     T.nS = T.nLive = T.hUsed = 0; T.kcur = T.n0cur = 0; T.zmode = false;
     return T;
 }
-// the same with the work arrays in LDS (W) when the input is small enough for them
+// the same with the work arrays in LDS (W).  Unconditional for a kernel that has them: a pointer that is LDS or global
+// depending on the input would make every access through it a flat_load / flat_store (clip_any sends larger solids to
+// clip_global instead).
 template <class LT, class LW>
-__device__ static Topo<InLds> lds_topo(Scratch& S, LT& L, LW* W, uint32_t nv_in)
+__device__ __attribute__((always_inline)) static inline Topo<InLds> lds_topo(Scratch& S, LT& L, LW* W)
 {
     Topo<InLds> T = lds_topo(S, L);
     if constexpr (LW::kN != 0)
     {
-        if (W != nullptr && nv_in <= LW::kN)
-        {
-            T.pos = W->pos; T.aux0 = W->aux0; T.aux1 = W->aux1; T.aux2 = W->aux2; T.gcomp = W->gcomp;
-            if (T.capV > LW::kN) T.capV = LW::kN;
-        }
+        T.pos = W->pos; T.aux0 = W->aux0; T.aux1 = W->aux1; T.aux2 = W->aux2; T.gcomp = W->gcomp;
+        if (T.capV > LW::kN) T.capV = LW::kN;
     }
     return T;
 }
@@ -232,13 +231,16 @@ __device__ static int clip_global(const SolidIn in, uint32_t F, Scratch& S, Shar
 
 // Clips `in` by sh.planes[0..F) and hands the resulting Topo (nLive == 0: empty) to `consume`.
 // Returns 0 or an error code (uniform over the workgroup).
+// (always inlined into the kernel: as a function it would get its LDS objects through generic pointers and every LDS access
+// would be a flat_load / flat_store)
 template <class LT, class Consume, class LW = NoLdsWork>
-__device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume, LW* W = nullptr)
+__device__ __attribute__((always_inline)) static inline int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume, LW* W = nullptr)
 {
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
-    int rc;
+    int rc = SURTR_OVERFLOW;
+    if (LW::kN == 0 || in.nv <= LW::kN)
     {
-        Topo<InLds> T = lds_topo(S, L, W, in.nv);
+        Topo<InLds> T = lds_topo(S, L, W);
         // pre-pass masks sit in the tail of the ring area while the reduced solid is being emitted
         // (the tail is free again afterwards); a copy of the bit mask goes to global scratch for the
         // all-in-plane corner case of clip_planes
@@ -252,7 +254,8 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
-        rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
+        if (LW::kN != 0 && in.nv <= LW::kN && in.nv <= SURTR_KEEPALL_V) rc = load_whole(in, F, T, sh);      // a Convex: no culling, no masks
+        else rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
@@ -284,7 +287,7 @@ __device__ static int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared&
 // The same from an image of the reduced solid (k_prep_pairs ran the pre-pass): load it into the LDS topology,
 // run the plane loop; a solid that outgrows the LDS topology is redone on global scratch from the input.
 template <class LT, class Consume>
-__device__ static int clip_image(const char* img, uint32_t n, uint32_t hsum, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
+__device__ __attribute__((always_inline)) static inline int clip_image(const char* img, uint32_t n, uint32_t hsum, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
                                  LT& L, Consume consume)
 {
     const uint32_t tid = threadIdx.x;
@@ -377,7 +380,7 @@ __global__ void k_place_cells_groups(uint32_t nfaces, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------- arena output
-__device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
+__device__ __attribute__((always_inline)) static inline bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
                                   uint32_t& voff, uint32_t& hoff, uint32_t& ioff)
 {
     __syncthreads();
@@ -396,7 +399,7 @@ __device__ static bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint3
 
 // Writes the clipped solid (one piece of output) to the arena.  Returns 0 / SURTR_E_CAPACITY.
 template <class TT>
-__device__ static int park_topo(Topo<TT>& T, Shared& sh, const Arena& A, uint32_t& voff, uint32_t& n, uint32_t& hoff, uint32_t& nh)
+__device__ __attribute__((always_inline)) static inline int park_topo(Topo<TT>& T, Shared& sh, const Arena& A, uint32_t& voff, uint32_t& n, uint32_t& hoff, uint32_t& nh)
 {
     const uint2 tot = index_live(T, sh);
     uint32_t ioff;
@@ -410,7 +413,7 @@ __device__ static int park_topo(Topo<TT>& T, Shared& sh, const Arena& A, uint32_
 // Islands of the clipped Mesh (CheckMeshIsland, Src/Surtr.cpp:2157-2201) + the island-major copy to the
 // arena (the re-indexing of m_fractureTask, :1474-1500).  Islands are numbered by their lowest vertex.
 template <class TT>
-__device__ static int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A, PairRec& rec)
+__device__ __attribute__((always_inline)) static inline int park_mesh_islands(Topo<TT>& T, Shared& sh, const Arena& A, PairRec& rec)
 {
     typedef typename TT::idx_t I;
     const uint32_t tid = threadIdx.x, nS = T.nS;
@@ -655,6 +658,15 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
             const float4* bs = P.mbsph + P.mbo[piece];
             const uint32_t nsb = (V + SURTR_SB - 1u) / SURTR_SB;
+            __syncthreads();
+            for (uint32_t k = tid; k < F; k += group_size())      // the margins of prepass_select (the Convex itself was loaded whole)
+            {
+                const float4 pk = sh.planes[k];
+                const float n1 = fabsf(pk.x) + fabsf(pk.y) + fabsf(pk.z);
+                const float n2 = sqrtf(pk.x * pk.x + pk.y * pk.y + pk.z * pk.z) * 1.0001f;
+                sh.pmar[k] = make_float4(n2 * 1.00101f, 1.0e-5f * fabsf(pk.w), 1.0e-5f * n1, 0.f);
+            }
+            __syncthreads();
             uint32_t und = 0;
             for (uint32_t sb = tid * 8u; sb < nsb; sb += group_size() * 8u)
             {
@@ -828,7 +840,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
 // Mesh of every pair whose Convex survived (:1470-1500): clip, islands, island-major copy to the arena.
 // One workgroup: pairs of cost classes cls_hi..cls_lo, heavy first (tickets from A.cursors[qcur]).
 template <class LT>
-__device__ static void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Pieces& P, const float4* __restrict__ planes,
+__device__ __attribute__((always_inline)) static inline void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Pieces& P, const float4* __restrict__ planes,
                                        const uint32_t* __restrict__ plane_off, uint32_t cell_begin, uint32_t n_pairs,
                                        const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
                                        const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
