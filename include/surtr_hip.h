@@ -94,9 +94,15 @@ int surtr_set_arena(surtr_ctx* ctx, uint64_t verts, uint64_t nbrs, uint64_t idx)
 /* Per-kernel timing with HIP events recorded on the work stream (the reference's TIMER_* phase
  * timers, Inc/pch.h:122-141, Src/Surtr.cpp:1917-1941).  ms[i] = duration of the last launch of
  * 0 clip_pairs (Mesh), 1 frag_table, 2 refit, 3 faces, 4 out_scan, 5 pack, 6 clip_convex, 7 prep_pairs,
- * 8 clip_pairs_big (clip_pairs runs beside it on an internal stream); -1 where not run. */
+ * 8 clip_pairs_big, 9 clip_pairs_half, 10 clip_pairs retry launch (0, 8 and 9 run side by side on the caller's and
+ * two internal streams); -1 where not run. */
 int surtr_set_profiling(surtr_ctx* ctx, int on);
 int surtr_kernel_times(surtr_ctx* ctx, float ms[16]);
+/* Diagnostic: the device-side counters of the last event (synchronises the stream).  out[0..3] arena use (vertices, ring
+ * entries, indices, islands), [5] status, [16+c] pairs of cost class c handed to k_clip_pairs(_big), [32+c] fragments of size
+ * class c, [48+c] pairs of pre-pass class c, [64+c] pairs of class c handed to k_clip_pairs_half, [64] pairs that outgrew
+ * its half-size LDS topology and were redone by k_clip_pairs. */
+int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128]);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Replaces compound.PieceVec (Inc/Surtr.h:113-134): n pieces, each a (Convex, Mesh)

@@ -86,7 +86,9 @@ struct Arena
     uint32_t capV, capH, capI, capIsl;
     uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=clip queue [5]=status [6]=refit queue [7]=faces queue [8]=convex queue
                          // [9]=pre-pass queue [10]=image arena (16-byte units) [11]=big clip queue
-                         // [16..31]=pairs per cost class (k_prep_pairs)
+                         // [12]=half clip queue [13]=retry queue
+                         // [16..31]=pairs per cost class (k_prep_pairs) [32..47]=fragments per size class [48..63]=pairs per
+                         // pre-pass class [64..79]=pairs per cost class of k_clip_pairs_half (64 = its retry list)
 };
 
 struct Pieces
@@ -167,6 +169,23 @@ struct alignas(16) LdsTopoT
 };
 typedef LdsTopoT<SURTR_LV, SURTR_LH> LdsTopo;          // Mesh solids: two workgroups of 256 threads per CU
 typedef LdsTopoT<2 * SURTR_LV, 2 * SURTR_LH> LdsTopoBig;   // the few Mesh solids with a large band: one workgroup per CU
+// Half-size topology for the light pairs: four workgroups of 128 threads per CU (LdsTopoHalf + Shared <= 40 KiB).  These
+// kernels are bound by dependent round trips, not by lanes: half the lanes cost a pair ~1.3x, twice the pairs in flight win.
+#define SURTR_LVS (SURTR_LV / 2u)
+#define SURTR_LHS ((SURTR_LH * 11u / 24u) & ~7u)
+#define SURTR_WGS (SURTR_WG / 2u > SURTR_LANES ? SURTR_WG / 2u : SURTR_LANES)
+typedef LdsTopoT<SURTR_LVS, SURTR_LHS> LdsTopoHalf;
+// The half-size topology takes solids of up to half its capacity: thin bands can double under the cuts (measured on
+// BASELINE configs[3]: a fifth of the pairs admitted with 20 % room outgrew it), and a retry costs the pair twice.
+#ifndef SURTR_HALF_ROOM
+#define SURTR_HALF_ROOM 2u       // (tests build with 1 to make pairs outgrow it)
+#endif
+__host__ __device__ static inline bool fits_half(uint32_t n, uint32_t h, uint32_t capVs) { return SURTR_HALF_ROOM * n <= capVs && SURTR_HALF_ROOM * h <= SURTR_LHS; }
+// does a solid of n vertices / h ring entries leave a topology of capV / capH room to grow by the cuts?
+__host__ __device__ static inline bool fits_with_room(uint32_t n, uint32_t h, uint32_t capV, uint32_t capH)
+{
+    return n + capV / 5u <= capV && h + capH / 6u <= capH;
+}
 #ifdef SURTR_EMUL
 typedef LdsTopoT<64, 512> LdsTopoSmall;                 // (emulation: small enough to exercise the fallback too)
 #else
@@ -233,7 +252,7 @@ __device__ static int clip_global(const SolidIn in, uint32_t F, Scratch& S, Shar
 // Returns 0 or an error code (uniform over the workgroup).
 // (always inlined into the kernel: as a function it would get its LDS objects through generic pointers and every LDS access
 // would be a flat_load / flat_store)
-template <class LT, class Consume, class LW = NoLdsWork>
+template <class LT, class Consume, class LW = NoLdsWork, bool GLOBAL_FALLBACK = true>
 __device__ __attribute__((always_inline)) static inline int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume, LW* W = nullptr)
 {
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
@@ -280,13 +299,13 @@ __device__ __attribute__((always_inline)) static inline int clip_any(const Solid
 #endif
         if (rc == 0) return consume(T);
     }
-    if (rc != SURTR_OVERFLOW) return rc;
+    if (rc != SURTR_OVERFLOW || !GLOBAL_FALLBACK) return rc;
     return clip_global(in, F, S, sh, consume);
 }
 
 // The same from an image of the reduced solid (k_prep_pairs ran the pre-pass): load it into the LDS topology,
 // run the plane loop; a solid that outgrows the LDS topology is redone on global scratch from the input.
-template <class LT, class Consume>
+template <bool GLOBAL_FALLBACK = true, class LT, class Consume>
 __device__ __attribute__((always_inline)) static inline int clip_image(const char* img, uint32_t n, uint32_t hsum, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
                                  LT& L, Consume consume)
 {
@@ -320,7 +339,7 @@ __device__ __attribute__((always_inline)) static inline int clip_image(const cha
         __syncthreads();
         if (rc == 0) return consume(T);
     }
-    if (rc != SURTR_OVERFLOW) return rc;
+    if (rc != SURTR_OVERFLOW || !GLOBAL_FALLBACK) return rc;
     return clip_global(in, F, S, sh, consume);
 }
 
@@ -717,13 +736,15 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #endif
 __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
-                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV,
+                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
-                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder)
+                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
+                                                         uint32_t* __restrict__ horder, uint32_t half_on)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
     auto enqueue = [&](uint32_t p, uint32_t cls) { order[(size_t)cls * n_pairs + atomicAdd(&A.cursors[16u + cls], 1u)] = p; };
+    auto enqueue_half = [&](uint32_t p, uint32_t cls) { horder[(size_t)cls * n_pairs + atomicAdd(&A.cursors[64u + cls], 1u)] = p; };
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
@@ -761,7 +782,16 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
-        if (V < SURTR_PREP_MINV || V > pool.VMAX) { if (tid == 0) enqueue(p, V > pool.VMAX ? 13u : 0u); continue; }
+        if (V < SURTR_PREP_MINV || V > pool.VMAX)
+        {
+            // not pre-passed here: the whole Mesh decides between the half-size kernel and the regular one
+            if (tid == 0)
+            {
+                if (half_on && V <= pool.VMAX && fits_half(V, P.mloff[m0 + V] - P.mloff[m0], capVs)) enqueue_half(p, 1u);
+                else enqueue(p, V > pool.VMAX ? 13u : 0u);
+            }
+            continue;
+        }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
@@ -821,11 +851,13 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             pairs[p].img_fmt = fmt; pairs[p].img_off = off16; pairs[p].img_n = n; pairs[p].img_h = hsum;
             // classes 14 and 15 go to k_clip_pairs_big: bands that leave the regular LDS topology little room to grow
             // (the first plane alone may add a thousand vertices), and solids beyond any LDS topology
+            // solids of at most half the half-size topology have their own table (k_clip_pairs_half)
             uint32_t cls = 15u;
             if (fmt == IMG_NONE) cls = 13u;
             else if (fmt == IMG_NARROW)
-                cls = (n + capV / 5u > capV || hsum + SURTR_LH / 6u > SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
-            if (fmt != IMG_EMPTY) enqueue(p, cls);
+                cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
+            if (half_on && fmt == IMG_NARROW && fits_half(n, hsum, capVs)) enqueue_half(p, cls < 6u ? cls : 6u);
+            else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; wg_work += d; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 7) bkt = 7; atomicAdd(&g_stamp[62 + bkt], 1ull); }
@@ -839,30 +871,40 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
 // -------------------------------------------------------------- k_clip_pairs
 // Mesh of every pair whose Convex survived (:1470-1500): clip, islands, island-major copy to the arena.
 // One workgroup: pairs of cost classes cls_hi..cls_lo, heavy first (tickets from A.cursors[qcur]).
-template <class LT>
+template <bool HALF = false, class LT>
 __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Pieces& P, const float4* __restrict__ planes,
                                        const uint32_t* __restrict__ plane_off, uint32_t cell_begin, uint32_t n_pairs,
                                        const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
                                        const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
-                                       int cls_hi, int cls_lo, uint32_t qcur)
+                                       uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
 {
     const uint32_t tid = threadIdx.x;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
+    // classes of the half table this launch takes: 6..1 (k_clip_pairs_half), its retry list (cls_hi < 0), or none
+    const int h_hi = HALF ? 6 : (cls_hi < 0 ? 0 : -1), h_lo = cls_hi < 0 ? 0 : 1;
     while (true)
     {
         __syncthreads();
         if (tid == 0)
         {
-            // next ticket -> pair (k_prep_pairs filled `order`)
+            // next ticket -> pair (k_prep_pairs filled the tables), heavy classes first
             uint32_t t = atomicAdd(&A.cursors[qcur], 1u), p = 0xFFFFFFFFu;
-            for (int cls = cls_hi; cls >= cls_lo; --cls)
-            {
-                const uint32_t cnt = A.cursors[16 + cls];
-                if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
-                t -= cnt;
-            }
+            if (!HALF)
+                for (int cls = cls_hi; cls >= cls_lo; --cls)
+                {
+                    const uint32_t cnt = A.cursors[16 + cls];
+                    if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
+                    t -= cnt;
+                }
+            if (p == 0xFFFFFFFFu)
+                for (int cls = h_hi; cls >= h_lo; --cls)
+                {
+                    const uint32_t cnt = A.cursors[64 + cls];
+                    if (t < cnt) { p = horder[(size_t)cls * n_pairs + t]; break; }
+                    t -= cnt;
+                }
             sh.misc[7] = p;
         }
         __syncthreads();
@@ -888,7 +930,20 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
             return park_mesh_islands(T, sh, A, rec);
         };
         int err;
-        if (rec.img_fmt == IMG_NARROW) err = clip_image(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+        if (HALF)
+        {
+            // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
+            // (class 0), which a second launch of k_clip_pairs picks up
+            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+            else err = clip_any<LT, decltype(consume), NoLdsWork, false>(min, F, S, sh, L, consume);
+            __syncthreads();
+            if (err == SURTR_OVERFLOW)
+            {
+                if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p;
+                continue;
+            }
+        }
+        else if (rec.img_fmt == IMG_NARROW) err = clip_image(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
         else if (rec.img_fmt == IMG_WIDE) err = clip_global(min, F, S, sh, consume);
         else err = clip_any(min, F, S, sh, L, consume);
         __syncthreads();
@@ -910,12 +965,27 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
                                                          ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
-                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order)
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
 {
     __shared__ Shared sh;
     __shared__ LdsTopo L;
     Scratch S = carve(pool, blockIdx.x);
-    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, 13, 0, 4u);
+    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, horder, cls_hi, cls_lo, qcur);
+}
+
+// The light pairs (cost classes 1..6: reduced solids that leave the half-size topology room to grow): half the
+// threads, half the LDS, four workgroups per CU; its own, smaller scratch pool.  Runs beside the other two.
+__global__ __launch_bounds__(SURTR_WGS) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_half(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, uint32_t* __restrict__ horder)
+{
+    __shared__ Shared sh;
+    __shared__ LdsTopoHalf L;
+    Scratch S = carve(pool, blockIdx.x);
+    clip_pairs_body<true>(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, nullptr, horder, 6, 1, 12u);
 }
 
 // The same with the double-size LDS topology (one workgroup per CU) for cost classes 14 and 15; runs beside
@@ -930,7 +1000,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
     __shared__ Shared sh;
     __shared__ LdsTopoBig L;
     Scratch S = carve(pool, wg_base + blockIdx.x);
-    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, 15, 14, 11u);
+    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, nullptr, 15, 14, 11u);
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -1832,7 +1902,12 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
 struct surtr_ctx
 {
     int device = 0;
-    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792;
+    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;
+    ScratchPool pool_half{}; uint32_t n_wg_half = 0;       // k_clip_pairs_half: scratch for the half-size LDS topology only
+    // Light pairs go to k_clip_pairs_half only when they are most of the event (small pieces: refracture).  Beside a
+    // full k_clip_pairs a third kernel costs more than it gains (configs[3]: +0.2 ms even when its workgroups exit at
+    // once), and what a large piece leaves of itself in a cell is seldom small enough.  Decided per upload from the piece sizes.
+    bool half_on = false;
     PrepPool prep{nullptr, 0, 0}; uint32_t n_wg_prep = 0;
     ImgArena img{nullptr, 0};
     uint32_t* d_order = nullptr; uint32_t cap_order = 0;
@@ -1840,7 +1915,8 @@ struct surtr_ctx
     uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
 #ifndef SURTR_EMUL
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
-    hipEvent_t ev_prep = nullptr, ev_big = nullptr;
+    hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both
+    hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr;
 #endif
     hipStream_t stream = nullptr;
     std::string err;
@@ -1940,6 +2016,9 @@ int surtr_create(int device, surtr_ctx** out)
             if (const char* e = getenv("SURTR_WG_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) per_cu = (uint32_t)v; }
             ctx->max_wg = (uint32_t)prop.multiProcessorCount * per_cu;
             ctx->max_wg_faces = (uint32_t)prop.multiProcessorCount * 4u;
+            uint32_t half_per_cu = 4u;
+            if (const char* e = getenv("SURTR_HALF_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) half_per_cu = (uint32_t)v; }
+            ctx->max_wg_half = (uint32_t)prop.multiProcessorCount * half_per_cu;
             uint32_t small_per_cu = 8u;
             if (const char* e = getenv("SURTR_SMALL_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) small_per_cu = (uint32_t)v; }
             ctx->max_wg_small = (uint32_t)prop.multiProcessorCount * small_per_cu;
@@ -1949,9 +2028,11 @@ int surtr_create(int device, surtr_ctx** out)
         }
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-    if (hipMalloc((void**)&ctx->arena.cursors, 256) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+    if (hipMalloc((void**)&ctx->arena.cursors, 512) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
 #ifndef SURTR_EMUL
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
 #endif
@@ -1970,10 +2051,12 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mperm); free_dev(ctx->d_cperm); free_dev(ctx->d_mbo); free_dev(ctx->d_cbo); free_dev(ctx->d_mpos_s); free_dev(ctx->d_cpos_s);
     free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
-    free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
 #ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->ev_half) (void)hipEventDestroy(ctx->ev_half);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     for (int i = 0; i < 32; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -2212,6 +2295,13 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const f
     if (rc) return rc;
     ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
     ctx->tot_mv = tv; ctx->tot_mh = th;
+    {
+        uint32_t small = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            if (fits_half((mvo[i + 1] - mvo[i]) / 4u, (moff[mvo[i + 1]] - moff[mvo[i]]) / 4u, SURTR_LVS)) ++small;      // what a cell keeps of it is likely light
+        ctx->half_on = 4ull * small >= 3ull * n;
+        if (const char* e = getenv("SURTR_HALF")) ctx->half_on = atoi(e) != 0;      // tests: force either way
+    }
     free_dev(ctx->pool_small.base); ctx->pool_small.base = nullptr;
     free_dev(ctx->pool.base); ctx->pool.base = nullptr;      // re-size scratch lazily
     free_dev(ctx->d_outside); ctx->d_outside = nullptr;
@@ -2309,6 +2399,19 @@ static int ensure_scratch_small(surtr_ctx* ctx, uint32_t n_wg)
     return SURTR_OK;
 }
 
+static int ensure_scratch_half(surtr_ctx* ctx, uint32_t n_wg)
+{
+    // k_clip_pairs_half never leaves its LDS topology: positions, work lists and squeeze staging for SURTR_LVS / SURTR_LHS
+    const uint32_t CV = SURTR_LVS + 256u, CH = SURTR_LHS + 256u, VMAX = SURTR_LVS + 64u;
+    if (ctx->pool_half.base && ctx->n_wg_half >= n_wg) return SURTR_OK;
+    free_dev(ctx->pool_half.base); ctx->pool_half.base = nullptr;
+    ctx->pool_half.CV = CV; ctx->pool_half.CH = CH; ctx->pool_half.VMAX = VMAX;
+    ctx->pool_half.per_wg = scratch_bytes_per_wg(CV, CH, VMAX);
+    ctx->n_wg_half = n_wg;
+    HIPCHK(hipMalloc((void**)&ctx->pool_half.base, ctx->pool_half.per_wg * n_wg));
+    return SURTR_OK;
+}
+
 // Scratch of k_prep_pairs and the arena its images go to.  An image is at most the LDS topology plus masks; when the
 // arena runs out, k_clip_pairs pre-passes the remaining pairs itself, so its size only matters for speed.
 static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
@@ -2323,7 +2426,7 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
     if (ctx->cap_order < n_pairs)
     {
         free_dev(ctx->d_order); ctx->d_order = nullptr;
-        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 32 * 4));      // two tables: clip order, pre-pass order
+        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 48 * 4));      // three tables: clip order, pre-pass order, half clip order
         ctx->cap_order = n_pairs;
     }
     const uint64_t full = (uint64_t)ctx->vmax * 16 + (uint64_t)ctx->hmax * 2;
@@ -2394,13 +2497,16 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     const uint32_t n_wg_small = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_small));
     rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
     if (rc) return rc;
+    const uint32_t n_wg_half = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_half));
+    rc = ensure_scratch_half(ctx, std::max(ctx->max_wg_half, ctx->n_wg_half));
+    if (rc) return rc;
     rc = ensure_arena(ctx, std::max(n_pairs, 1u));
     if (rc) return rc;
     const uint32_t n_wg_prep = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_prep));
     rc = ensure_prep(ctx, std::max(n_pairs, 1u), std::max(n_wg_prep, ctx->n_wg_prep));
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 256, st));
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 512, st));
     HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
     const uint8_t* d_out = nullptr;
     if (outside)
@@ -2419,16 +2525,18 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_BEGIN(7);
     if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order);
+                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
-    // are placed before k_clip_pairs (second stream) fills the CUs two by two; both run side by side.
+    // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
 #ifndef SURTR_EMUL
-    hipStream_t st2 = ctx->stream2;
+    hipStream_t st2 = ctx->stream2, st3 = ctx->stream3;
     HIPCHK(hipEventRecord(ctx->ev_prep, st));
     HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
+    HIPCHK(hipStreamWaitEvent(st3, ctx->ev_prep, 0));
 #else
-    hipStream_t st2 = st;
+    hipStream_t st2 = st, st3 = st;
 #endif
     PROF_BEGIN(8);
     if (n_pairs)
@@ -2438,8 +2546,24 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_BEGIN_ON(0, st2);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
     PROF_END_ON(0, st2);
+    PROF_BEGIN_ON(9, st3);
+    if (n_pairs && ctx->half_on)
+        hipLaunchKernelGGL(k_clip_pairs_half, dim3(n_wg_half), dim3(SURTR_WGS), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool_half, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)32 * ctx->cap_order);
+    PROF_END_ON(9, st3);
+#ifndef SURTR_EMUL
+    HIPCHK(hipEventRecord(ctx->ev_half, st3));
+    HIPCHK(hipStreamWaitEvent(st2, ctx->ev_half, 0));
+#endif
+    // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
+    // (it reuses the scratch slots of the first launch)
+    PROF_BEGIN_ON(10, st2);
+    if (n_pairs && ctx->half_on)
+        hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
+    PROF_END_ON(10, st2);
 #ifndef SURTR_EMUL
     HIPCHK(hipEventRecord(ctx->ev_big, st2));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
@@ -2640,6 +2764,15 @@ int surtr_kernel_times(surtr_ctx* ctx, float ms[16])
     for (int i = 0; i < 16; ++i)
         if (ctx->ev_valid[i]) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ms[i] = t; }
 #endif
+    return SURTR_OK;
+}
+
+int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128])
+{
+    if (!ctx || !out) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out, ctx->arena.cursors, 512, hipMemcpyDeviceToHost));
     return SURTR_OK;
 }
 

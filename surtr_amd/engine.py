@@ -133,8 +133,14 @@ class Engine:
     def kernel_times(self):
         ms = (ctypes.c_float * 16)()
         self._ck(lib().surtr_kernel_times(self._h, ms))
-        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big")
+        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry")
         return {n: float(ms[i]) for i, n in enumerate(names)}
+
+    def queue_stats(self):
+        """Device-side counters of the last event (include/surtr_hip.h: surtr_queue_stats)."""
+        out = (ctypes.c_uint32 * 128)()
+        self._ck(lib().surtr_queue_stats(self._h, out))
+        return np.frombuffer(out, dtype=np.uint32).copy()
 
     def upload_pieces(self, meshes, convexes):
         assert len(meshes) == len(convexes)

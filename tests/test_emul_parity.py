@@ -268,3 +268,33 @@ def test_degenerate_ach_of_a_box_is_refused(emul_engine):
     eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
     assert eng.fracture_event(0, 8).n_frag == 8
     eng.close()
+
+
+@pytest.mark.parametrize("which,tiny", [("cube", False), ("blob", False), ("torus", False), ("torus12", True), ("torus16", True)])
+def test_half_size_kernel_and_its_retry_list(emul_lib_path, oracle, monkeypatch, which, tiny):
+    """k_clip_pairs_half (light pairs, half-size LDS topology) forced on: same event.  In the tiny-capacity build it admits
+    solids with no room to grow, so pairs outgrow it and are redone by the retry launch of k_clip_pairs."""
+    monkeypatch.setenv("SURTR_HALF", "1")
+    sc = {"cube": lambda: scenes.cube_scene(8), "blob": lambda: scenes.blob_scene(64),
+          "torus": lambda: scenes.make_scene(*meshgen.bumpy_torus(40, 24), 24),
+          "torus12": lambda: scenes.make_scene(*meshgen.bumpy_torus(12, 8), 6),
+          "torus16": lambda: scenes.make_scene(*meshgen.bumpy_torus(16, 10), 12)}[which]()
+    cells = sc["n_cells"]
+    from surtr_amd import engine as E
+    E._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), "libsurtr_emul_small.so" if tiny else "libsurtr_emul.so"))
+    try:
+        eng = E.Engine(0)
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+        c = eng.fracture_event(0, cells, flags=3)
+        got = eng.download()
+        qs = eng.queue_stats()
+        eng.close()
+    finally:
+        E._use_library_for_tests(None)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=True, render=True, threads=4, cell_end=cells)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    assert qs[65:71].sum() > 0, "no pair went to the half-size kernel"
+    if tiny:
+        assert qs[64] > 0, "the retry list was not exercised"

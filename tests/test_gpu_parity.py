@@ -78,6 +78,26 @@ def test_blob_configs(gpu_engine, oracle, name, n):
     assert abs(float(got["mesh_pos"].astype(np.float64).sum()) - want["mesh_pos_sum"]) <= 1e-5 * abs(want["mesh_pos_sum"]) + 1e-3
 
 
+@pytest.mark.parametrize("which", ["blob1024", "torus512"])
+def test_half_size_kernel_forced_on(gpu_engine, oracle, monkeypatch, which):
+    """k_clip_pairs_half is chosen per upload from the piece sizes (small pieces: refracture); forced on here for large
+    pieces too: light pairs take the half-size LDS topology, the others the regular kernel beside it, same event."""
+    monkeypatch.setenv("SURTR_HALF", "1")
+    sc = scenes.blob_scene(1024) if which == "blob1024" else scenes.torus_scene(4096)
+    cells = 1024 if which == "blob1024" else 512
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+    c = eng.fracture_event(0, cells, flags=3)
+    got = eng.download()
+    qs = eng.queue_stats()
+    eng.close()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=True, render=True, threads=16, cell_end=cells)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    assert qs[65:71].sum() > 0, "no pair went to the half-size kernel"
+
+
 def test_torus_4096_full_event_vs_oracle_and_digest(torus_run):
     sc, c, got, ref = torus_run
     assert c.status == 0 and c.n_pairs == 4096
