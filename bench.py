@@ -4,7 +4,9 @@
 
 A "step" is one fracture event per GPU on device-resident inputs: cell placement (A3), clip of Convex and
 Mesh against every cell + island split (A7, A8, A11), refit (A12), face extraction + ear clipping
-(A9, A10), pack of the fragment blob, and -- for N > 1 -- one all-gather of the blobs over RCCL.
+(A9, A10), pack of the fragment blob, and -- for N > 1 -- one all-gather of the blobs over RCCL, issued on
+RCCL's stream so that it runs beside the kernels of the next event (two blob buffers); the timed region ends
+with every gather complete.
 
 Scaling: the path partitions into independent (cell, piece) units, so by default every rank gets a FIXED
 share -- one 4096-cell pattern of its own (seed 46354 + rank; rank 0 is exactly BASELINE configs[3]) -- and
@@ -105,16 +107,39 @@ def main():
         cap = (int(cap_t.item()) + 4095) // 4096 * 4096
         blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
         gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if world > 1 else blob
+        # N > 1: two blob / gather buffers, so that the all-gather of event i (RCCL's stream) runs beside the kernels of
+        # event i+1 (this stream).  Event i+2 waits for gather i before it packs into the same blob.  `blob`/`gathered`
+        # are buffer 0; the caller reads them after an even number of steps or after `drain()`.
+        bufs = [(blob, gathered)]
+        if world > 1:
+            bufs.append((torch.zeros_like(blob), torch.zeros_like(gathered)))
+        state = {"i": 0}
 
         def step():
+            k = state["i"] % len(bufs)
+            state["i"] += 1
+            b, g = bufs[k]
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
             eng.place_cells(sc["scale"], sc["translate"])
             eng.fracture_event_async(cb, ce, flags=flags)
-            eng.pack_dev(blob.data_ptr(), cap)
+            eng.pack_dev(b.data_ptr(), cap)
             if world > 1:
-                dist.all_gather_into_tensor(gathered, blob)
-        return sc, eng, step, blob, gathered, cap, (cb, ce)
+                pending[k] = dist.all_gather_into_tensor(g, b, async_op=True)
+
+        def last():
+            """(blob, gathered) of the most recent step."""
+            return bufs[(state["i"] - 1) % len(bufs)]
+        return sc, eng, step, last, cap, (cb, ce)
+
+    pending = [None, None]
 
     def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -132,8 +157,9 @@ def main():
             dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         return float(dt_t.item())
 
-    sc, eng, step, blob, gathered, cap, (cb, ce) = setup(args.scaling)
+    sc, eng, step, last, cap, (cb, ce) = setup(args.scaling)
     dt = timed(step, args.warmup, args.steps)
+    blob, gathered = last()
 
     # fragment totals over ranks (from the gathered blob headers)
     host = gathered.cpu().numpy()
@@ -163,10 +189,10 @@ def main():
     if world > 1 and args.scaling == "weak":
         # the same run also times BASELINE configs[3] as ONE event sharded over the ranks (strong scaling)
         eng.close()
-        sc2, eng2, step2, blob2, gathered2, cap2, _ = setup("strong")
+        sc2, eng2, step2, last2, cap2, _ = setup("strong")
         k2 = max(3, min(args.steps, 10))
         dt2 = timed(step2, 2, k2)
-        host2 = gathered2.cpu().numpy()
+        host2 = last2()[1].cpu().numpy()
         nf2 = sum(engine.unpack_blob(host2[r * cap2:(r + 1) * cap2])[0].n_frag for r in range(world))
         strong_extra = {"ms_per_event": dt2 / k2 * 1e3, "fragments": nf2, "fragments_per_s": nf2 / (dt2 / k2), "steps": k2}
         eng2.close()
