@@ -1,0 +1,20 @@
+"""Times the cell blocks a rank of an N-way strong-sharded configs[3] event would run (one GPU, block by block)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from surtr_amd import engine as E, scenes as S
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+sc = S.torus_scene(4096)
+eng = E.Engine(0)
+sc["convex"], _ = S.ach_convex(eng, sc["mesh"]["pos"])
+eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+eng.fracture_event(0, 4096)
+eng.set_profiling(True)
+for r in range(N):
+    cb, ce = E.cell_block(r, N, 4096)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter(); c = eng.fracture_event(cb, ce); ts.append((time.perf_counter() - t0) * 1e3)
+    kt = eng.kernel_times()
+    print("rank %d of %d: cells [%d,%d) frags %d event ms %.2f" % (r, N, cb, ce, c.n_frag, min(ts)), {k: round(v, 3) for k, v in kt.items() if v >= 0}, flush=True)
+eng.close()

@@ -334,8 +334,9 @@ __device__ __forceinline__ int32_t face_next_in(const int32_t* ring, uint32_t le
 // the one insertion goes to the front (:404-408) whenever it happens.  The caller writes those rings afterwards;
 // here an insertion into an easy vertex is skipped.  wcur/wprev: end and last hop of the walk of every new vertex
 // (from the dry run -- walks only cross clipped vertices, whose rings the relink never changes).
+// (T by value: a reference would force the caller's Topo into every lane's private memory for the whole plane loop.)
 template <class TT>
-__device__ void relink_serial(Topo<TT>& T, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
+__device__ void relink_serial(const Topo<TT> T, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
                               const uint32_t* zlist, uint32_t nz, const uint32_t* slist, uint32_t ns,
                               const uint32_t* wcur, const uint32_t* wprev, const uint32_t* arrive, const uint32_t* srcof, Shared& sh)
 {

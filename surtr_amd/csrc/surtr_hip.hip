@@ -252,7 +252,7 @@ __device__ static int clip_global(const SolidIn in, uint32_t F, Scratch& S, Shar
 // Returns 0 or an error code (uniform over the workgroup).
 // (always inlined into the kernel: as a function it would get its LDS objects through generic pointers and every LDS access
 // would be a flat_load / flat_store)
-template <class LT, class Consume, class LW = NoLdsWork, bool GLOBAL_FALLBACK = true>
+template <bool GLOBAL_FALLBACK = true, class LT, class Consume, class LW = NoLdsWork>
 __device__ __attribute__((always_inline)) static inline int clip_any(const SolidIn in, uint32_t F, Scratch& S, Shared& sh, LT& L, Consume consume, LW* W = nullptr)
 {
     const uint32_t nbV = (in.nv + SURTR_LANES - 1u) >> SURTR_LSH;
@@ -344,6 +344,7 @@ __device__ __attribute__((always_inline)) static inline int clip_image(const cha
 }
 
 // ------------------------------------------------------------- small helpers
+struct ParkOut { int err; uint32_t voff, n, hoff, nh; };
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     float t = ax * bx + ay * by;
@@ -622,6 +623,20 @@ __device__ __attribute__((always_inline)) static inline int park_mesh_islands(To
 
 // ------------------------------------------------------------- k_clip_convex
 // Convex of every (cell, piece) pair first (Src/Surtr.cpp:1466-1468): small solids, one wave per task.
+// A solid of the one-wave kernels on global scratch (it does not fit their LDS topology; rare).  Out of line and with
+// every argument by value, see pair_global.
+__device__ __attribute__((noinline)) static ParkOut solid_global(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp)
+{
+    Shared& sh = *shp;
+    Scratch S = carve(pool, wg);
+    ParkOut o{0, 0u, 0u, 0u, 0u};
+    o.err = clip_global(in, F, S, sh, [&](auto& T) -> int {
+        if (T.nLive == 0) return 0;
+        return park_topo(T, sh, A, o.voff, o.n, o.hoff, o.nh);
+    });
+    return o;
+}
+
 #ifndef SURTR_SMALL_WAVES
 #define SURTR_SMALL_WAVES 2
 #endif
@@ -661,11 +676,17 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             const uint32_t c0 = P.cvo[piece];
             SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
                         P.cperm + c0, P.cpos_s + 3 * (size_t)c0, P.crad_s + c0, P.cbsph + P.cbo[piece]};
-            err = clip_any(cin, F, S, sh, L, [&](auto& T) -> int {
+            err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
                 if (T.nLive == 0) return 0;
                 return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
             }, &W);
             __syncthreads();
+            if (err == SURTR_OVERFLOW)
+            {
+                const ParkOut o = solid_global(cin, F, pool, blockIdx.x, A, &sh);
+                err = o.err; rec.cv_off = o.voff; rec.cv_n = o.n; rec.ch_off = o.hoff; rec.ch_n = o.nh;
+                __syncthreads();
+            }
         }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
@@ -871,14 +892,38 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
 // -------------------------------------------------------------- k_clip_pairs
 // Mesh of every pair whose Convex survived (:1470-1500): clip, islands, island-major copy to the arena.
 // One workgroup: pairs of cost classes cls_hi..cls_lo, heavy first (tickets from A.cursors[qcur]).
+// The Mesh of pair p on global scratch (32-bit topology): solids that do not fit, or outgrew, the LDS topology.  Rare, so
+// out of line and with every argument by value: nothing of the caller's state has to live in memory for it (structures
+// handed over by reference would be written to every lane's private scratch once per pair).  Stores pairs[p] itself.
+__device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t piece, uint32_t F, ScratchPool pool, uint32_t wg, Arena A,
+                                                            Shared* shp, PairRec* pairs, uint32_t p)
+{
+    Shared& sh = *shp;
+    Scratch S = carve(pool, wg);
+    PairRec rec = pairs[p];
+    const uint32_t m0 = P.mvo[piece];
+    SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
+                P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+    auto consume = [&](auto& T) -> int {
+        if (T.nLive == 0) return 0;
+        return park_mesh_islands(T, sh, A, rec);
+    };
+    const int err = clip_global(min, F, S, sh, consume);
+    __syncthreads();
+    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (threadIdx.x == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+    if (threadIdx.x == 0) pairs[p] = rec;
+    return err;
+}
+
 template <bool HALF = false, class LT>
-__device__ __attribute__((always_inline)) static inline void clip_pairs_body(Shared& sh, LT& L, Scratch& S, const Pieces& P, const float4* __restrict__ planes,
+__device__ __attribute__((always_inline)) static inline void clip_pairs_body(Shared& sh, LT& L, const ScratchPool& pool, uint32_t wg, const Pieces& P, const float4* __restrict__ planes,
                                        const uint32_t* __restrict__ plane_off, uint32_t cell_begin, uint32_t n_pairs,
                                        const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
                                        const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
                                        uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
 {
     const uint32_t tid = threadIdx.x;
+    Scratch S = carve(pool, wg);
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
@@ -935,7 +980,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
             // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
             // (class 0), which a second launch of k_clip_pairs picks up
             if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
-            else err = clip_any<LT, decltype(consume), NoLdsWork, false>(min, F, S, sh, L, consume);
+            else err = clip_any<false>(min, F, S, sh, L, consume);
             __syncthreads();
             if (err == SURTR_OVERFLOW)
             {
@@ -943,10 +988,18 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
                 continue;
             }
         }
-        else if (rec.img_fmt == IMG_NARROW) err = clip_image(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
-        else if (rec.img_fmt == IMG_WIDE) err = clip_global(min, F, S, sh, consume);
-        else err = clip_any(min, F, S, sh, L, consume);
-        __syncthreads();
+        else
+        {
+            err = SURTR_OVERFLOW;
+            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+            else if (rec.img_fmt != IMG_WIDE) err = clip_any<false>(min, F, S, sh, L, consume);
+            __syncthreads();
+            if (err == SURTR_OVERFLOW)
+            {
+                pair_global(P, piece, F, pool, wg, A, &sh, pairs, p);
+                continue;
+            }
+        }
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -970,8 +1023,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
 {
     __shared__ Shared sh;
     __shared__ LdsTopo L;
-    Scratch S = carve(pool, blockIdx.x);
-    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, horder, cls_hi, cls_lo, qcur);
+    clip_pairs_body(sh, L, pool, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, horder, cls_hi, cls_lo, qcur);
 }
 
 // The light pairs (cost classes 1..6: reduced solids that leave the half-size topology room to grow): half the
@@ -984,8 +1036,7 @@ __global__ __launch_bounds__(SURTR_WGS) __attribute__((amdgpu_waves_per_eu(2, 4)
 {
     __shared__ Shared sh;
     __shared__ LdsTopoHalf L;
-    Scratch S = carve(pool, blockIdx.x);
-    clip_pairs_body<true>(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, nullptr, horder, 6, 1, 12u);
+    clip_pairs_body<true>(sh, L, pool, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, nullptr, horder, 6, 1, 12u);
 }
 
 // The same with the double-size LDS topology (one workgroup per CU) for cost classes 14 and 15; runs beside
@@ -999,8 +1050,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
 {
     __shared__ Shared sh;
     __shared__ LdsTopoBig L;
-    Scratch S = carve(pool, wg_base + blockIdx.x);
-    clip_pairs_body(sh, L, S, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, nullptr, 15, 14, 11u);
+    clip_pairs_body(sh, L, pool, wg_base + blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, nullptr, 15, 14, 11u);
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -1226,11 +1276,17 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
-        int err = clip_any(cin, 8, S, sh, L, [&](auto& T) -> int {
+        int err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
         }, &W);
         __syncthreads();
+        if (err == SURTR_OVERFLOW)
+        {
+            const ParkOut o = solid_global(cin, 8, pool, blockIdx.x, A, &sh);
+            err = o.err; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh;
+            __syncthreads();
+        }
         if (err == 0 && tid == 0)
         {
             // field-wise: k_faces updates other fields of the same record at the same time
