@@ -57,7 +57,13 @@ def main():
     ap.add_argument("--cells", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, all-gather) with one rank")
     args = ap.parse_args()
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner under
+    # NCCL_DEBUG=VERSION) are sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -70,15 +76,17 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if not os.path.exists(os.path.join(ROOT, "surtr_amd", "libsurtr_hip.so")):
         import __graft_entry__
         if rank == 0:
             __graft_entry__.build()
-        if world > 1:
+        if multi:
             dist.barrier()
     from surtr_amd import engine, scenes, multigpu
 
@@ -102,16 +110,16 @@ def main():
         eng.place_cells(sc["scale"], sc["translate"])
         counts = eng.fracture_event(cb, ce, flags=flags)
         cap_t = torch.tensor([engine.blob_bytes(counts)], dtype=torch.int64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         cap = (int(cap_t.item()) + 4095) // 4096 * 4096
         blob = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if world > 1 else blob
+        gathered = torch.zeros(world * cap, dtype=torch.uint8, device=dev) if multi else blob
         # N > 1: two blob / gather buffers, so that the all-gather of event i (RCCL's stream) runs beside the kernels of
         # event i+1 (this stream).  Event i+2 waits for gather i before it packs into the same blob.  `blob`/`gathered`
         # are buffer 0; the caller reads them after an even number of steps or after `drain()`.
         bufs = [(blob, gathered)]
-        if world > 1:
+        if multi:
             bufs.append((torch.zeros_like(blob), torch.zeros_like(gathered)))
         state = {"i": 0}
 
@@ -125,7 +133,7 @@ def main():
             eng.place_cells(sc["scale"], sc["translate"])
             eng.fracture_event_async(cb, ce, flags=flags)
             eng.pack_dev(b.data_ptr(), cap)
-            if world > 1:
+            if multi:
                 pending[k] = dist.all_gather_into_tensor(g, b, async_op=True)
 
         def last():
@@ -140,7 +148,7 @@ def main():
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +161,7 @@ def main():
             step()
         fence()
         dt_t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        if world > 1:
+        if multi:
             dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         return float(dt_t.item())
 
@@ -186,7 +194,7 @@ def main():
     eng.set_profiling(False)
 
     strong_extra = None
-    if world > 1 and args.scaling == "weak":
+    if multi and args.scaling == "weak":
         # the same run also times BASELINE configs[3] as ONE event sharded over the ranks (strong scaling)
         eng.close()
         sc2, eng2, step2, last2, cap2, _ = setup("strong")
@@ -256,9 +264,9 @@ def main():
             out["parity_check"] = {"fragments_gpu": total_frag, "fragments_cpu": nref,
                                    "mesh_nbr_equal": bool(np.array_equal(parts[0][1]["mesh_nbr"], ref["mesh_nbr"])),
                                    "idx_equal": bool(np.array_equal(parts[0][1]["idx"], ref["idx"]))}
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     eng.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
