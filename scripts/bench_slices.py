@@ -5,6 +5,7 @@ import numpy as np
 from surtr_amd import engine as E, scenes as S
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 sc = S.torus_scene(4096)
+if os.environ.get("SURTR_LIB"): E._use_library_for_tests(os.path.abspath(os.environ["SURTR_LIB"]))
 eng = E.Engine(0)
 sc["convex"], _ = S.ach_convex(eng, sc["mesh"]["pos"])
 eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
