@@ -37,8 +37,9 @@ struct PairRec
     uint32_t mv_off, mv_n, mh_off, mh_n;   // clipped Mesh (all islands, island-major)
     uint32_t ni, isl_off;                  // islands and where their (nv, nh) records start
     uint32_t status;
-    // reduced Mesh left in HBM by k_prep_pairs: img_fmt = IMG_*, offset in 16-byte units, vertices, ring entries
-    uint32_t img_fmt, img_off, img_n, img_h, pad;
+    // reduced Mesh left in HBM by k_prep_pairs: img_fmt = IMG_*, offset in 16-byte units, vertices, ring entries,
+    // position slots reserved (>= the capacity of the topology that will clip it: positions are then used in place)
+    uint32_t img_fmt, img_off, img_n, img_h, img_pc;
 };
 
 enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
@@ -49,13 +50,13 @@ enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
 // Byte offsets of the sections of one image (all 16-byte aligned): hist/zhist/nzero (F words each), the keep mask
 // (one word per 64 input vertices), then the reduced solid in the LDS layout, then its positions.
 struct ImgLayout { uint32_t hist, zhist, nzero, mask, loff, llen, comp, ring, pos, total; };
-__host__ __device__ static inline ImgLayout img_layout(uint32_t F, uint32_t nbV, uint32_t n, uint32_t hsum)
+__host__ __device__ static inline ImgLayout img_layout(uint32_t F, uint32_t nbV, uint32_t n, uint32_t hsum, uint32_t posCap = 0)
 {
     auto up = [](uint32_t b) { return (b + 15u) & ~15u; };
     ImgLayout L;
     L.hist = 0; L.zhist = up(4u * F); L.nzero = L.zhist + up(4u * F); L.mask = L.nzero + up(4u * F); L.loff = L.mask + up(8u * nbV);
     L.llen = L.loff + up(2u * n); L.comp = L.llen + up(n); L.ring = L.comp + up(n); L.pos = L.ring + up(2u * hsum);
-    L.total = L.pos + up(12u * n);
+    L.total = L.pos + up(12u * (n > posCap ? n : posCap));      // positions last: room for the cut points of the clip
     return L;
 }
 
@@ -306,7 +307,7 @@ __device__ __attribute__((always_inline)) static inline int clip_any(const Solid
 // The same from an image of the reduced solid (k_prep_pairs ran the pre-pass): load it into the LDS topology,
 // run the plane loop; a solid that outgrows the LDS topology is redone on global scratch from the input.
 template <bool GLOBAL_FALLBACK = true, class LT, class Consume>
-__device__ __attribute__((always_inline)) static inline int clip_image(const char* img, uint32_t n, uint32_t hsum, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
+__device__ __attribute__((always_inline)) static inline int clip_image(char* img, uint32_t n, uint32_t hsum, uint32_t posCap, const SolidIn in, uint32_t F, Scratch& S, Shared& sh,
                                  LT& L, Consume consume)
 {
     const uint32_t tid = threadIdx.x;
@@ -331,7 +332,9 @@ __device__ __attribute__((always_inline)) static inline int clip_image(const cha
         copy_words(L.llen, img + lay.llen, n);
         copy_words(L.fc, img + lay.comp, n);
         copy_words(L.ring, img + lay.ring, 2u * hsum);
-        copy_words(S.pos, img + lay.pos, 12u * n);
+        // positions: in place when k_prep_pairs reserved room for this topology's cut points (the usual case), else a copy
+        if (posCap >= T.capV) T.pos = (float*)(img + lay.pos);
+        else copy_words(S.pos, img + lay.pos, 12u * n);
         T.nS = n; T.nLive = n; T.hUsed = hsum;
         __syncthreads();
         STAMP(84);
@@ -838,7 +841,10 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         uint32_t fmt = IMG_NARROW, off16 = 0;
         if (n == 0) fmt = IMG_EMPTY;
         else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
-        const ImgLayout lay = img_layout(F, nbV, n, hsum);
+        // room for the cut points behind the positions, for the topology of the kernel that will take the pair
+        const bool to_half = half_on && fits_half(n, hsum, capVs);
+        const uint32_t posCap = to_half ? capVs : (fits_with_room(n, hsum, capV, SURTR_LH) ? capV : 2u * capV);
+        const ImgLayout lay = img_layout(F, nbV, n, hsum, posCap);
         if (fmt == IMG_NARROW)
         {
             const uint32_t need16 = lay.total / 16u;
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         }
         if (tid == 0)
         {
-            pairs[p].img_fmt = fmt; pairs[p].img_off = off16; pairs[p].img_n = n; pairs[p].img_h = hsum;
+            pairs[p].img_fmt = fmt; pairs[p].img_off = off16; pairs[p].img_n = n; pairs[p].img_h = hsum; pairs[p].img_pc = posCap;
             // classes 14 and 15 go to k_clip_pairs_big: bands that leave the regular LDS topology little room to grow
             // (the first plane alone may add a thousand vertices), and solids beyond any LDS topology
             // solids of at most half the half-size topology have their own table (k_clip_pairs_half)
@@ -877,7 +883,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             if (fmt == IMG_NONE) cls = 13u;
             else if (fmt == IMG_NARROW)
                 cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
-            if (half_on && fmt == IMG_NARROW && fits_half(n, hsum, capVs)) enqueue_half(p, cls < 6u ? cls : 6u);
+            if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -979,7 +985,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         {
             // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
             // (class 0), which a second launch of k_clip_pairs picks up
-            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, rec.img_pc, min, F, S, sh, L, consume);
             else err = clip_any<false>(min, F, S, sh, L, consume);
             __syncthreads();
             if (err == SURTR_OVERFLOW)
@@ -991,7 +997,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         else
         {
             err = SURTR_OVERFLOW;
-            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, min, F, S, sh, L, consume);
+            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, rec.img_pc, min, F, S, sh, L, consume);
             else if (rec.img_fmt != IMG_WIDE) err = clip_any<false>(min, F, S, sh, L, consume);
             __syncthreads();
             if (err == SURTR_OVERFLOW)
