@@ -332,7 +332,9 @@ __device__ __attribute__((always_inline)) static inline int clip_image(char* img
         copy_words(L.llen, img + lay.llen, n);
         copy_words(L.fc, img + lay.comp, n);
         copy_words(L.ring, img + lay.ring, 2u * hsum);
-        // positions: in place when k_prep_pairs reserved room for this topology's cut points (the usual case), else a copy
+        // positions: in place when k_prep_pairs reserved room for this topology's cut points (the usual case), else a copy.
+        // In place means the image is consumed (squeeze() compacts positions where they are): only for callers that never
+        // hand the pair to another pass over the same image (k_clip_pairs_half does: its retry list; it passes posCap = 0).
         if (posCap >= T.capV) T.pos = (float*)(img + lay.pos);
         else copy_words(S.pos, img + lay.pos, 12u * n);
         T.nS = n; T.nLive = n; T.hUsed = hsum;
@@ -843,7 +845,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
         // room for the cut points behind the positions, for the topology of the kernel that will take the pair
         const bool to_half = half_on && fits_half(n, hsum, capVs);
-        const uint32_t posCap = to_half ? capVs : (fits_with_room(n, hsum, capV, SURTR_LH) ? capV : 2u * capV);
+        // (none for the half-size kernel: it works on a copy, so that its retry list finds the image as it was)
+        const uint32_t posCap = to_half ? 0u : (fits_with_room(n, hsum, capV, SURTR_LH) ? capV : 2u * capV);
         const ImgLayout lay = img_layout(F, nbV, n, hsum, posCap);
         if (fmt == IMG_NARROW)
         {
@@ -985,7 +988,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         {
             // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
             // (class 0), which a second launch of k_clip_pairs picks up
-            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, rec.img_pc, min, F, S, sh, L, consume);
+            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, 0u, min, F, S, sh, L, consume);
             else err = clip_any<false>(min, F, S, sh, L, consume);
             __syncthreads();
             if (err == SURTR_OVERFLOW)

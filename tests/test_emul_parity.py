@@ -298,3 +298,31 @@ def test_half_size_kernel_and_its_retry_list(emul_lib_path, oracle, monkeypatch,
     assert qs[65:71].sum() > 0, "no pair went to the half-size kernel"
     if tiny:
         assert qs[64] > 0, "the retry list was not exercised"
+
+
+def test_retry_after_the_half_size_kernel_squeezed(emul_lib_path, oracle, monkeypatch):
+    """Pairs that outgrow the half-size topology after a few planes (and a squeeze) are redone from the image by the
+    retry launch: the image must still be what k_prep_pairs wrote (the half-size kernel works on a copy of its positions;
+    the other kernels use them in place).  Random small tori in a medium-capacity build; caught a real bug."""
+    monkeypatch.setenv("SURTR_HALF", "1")
+    from surtr_amd import engine as E
+    E._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), "libsurtr_emul_mid.so"))
+    rng = np.random.default_rng(5)
+    retried = 0
+    try:
+        for case in range(16):
+            nu, nv, cells = int(rng.integers(10, 40)), int(rng.integers(8, 24)), int(rng.choice([4, 6, 9, 14]))
+            sc = scenes.make_scene(*meshgen.bumpy_torus(nu, nv), cells, seeds=scenes.uniform_seeds(cells, int(rng.integers(1, 1 << 30))))
+            eng = E.Engine(0)
+            eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+            c = eng.fracture_event(0, cells, flags=3)
+            got = eng.download()
+            retried += int(eng.queue_stats()[64])
+            eng.close()
+            planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+            ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=True, render=True, threads=4, cell_end=cells)
+            assert c.status == 0
+            assert_event_equal(got, ref)
+    finally:
+        E._use_library_for_tests(None)
+    assert retried > 5
