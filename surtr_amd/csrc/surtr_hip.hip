@@ -1,13 +1,14 @@
 // surtr_hip.hip -- kernels of the fracture event + the C ABI of include/surtr_hip.h.
 //
-// Event pipeline (on the caller's HIP stream plus one internal stream for the kernels that may overlap -- k_clip_pairs beside
-// k_clip_pairs_big, k_refit beside k_faces -- fenced by events; inputs resident in HBM):
+// Event pipeline (on the caller's HIP stream plus two internal streams for the kernels that may overlap -- k_clip_pairs and
+// k_clip_pairs_half beside k_clip_pairs_big, k_refit beside k_faces -- fenced by events; inputs resident in HBM):
 //   k_place_cells   A3   Polygon3D::Scale/Translate + ConstructFacePlane      (Src/VMACH.cpp:302-310, 506-534)
 //   k_clip_convex   A7   Convex of every (cell, piece) pair, one wave per task (Src/Surtr.cpp:1466-1468)
 //   k_prep_pairs    A7   pre-pass of the Mesh of every pair whose Convex survived: the vertices the planes can touch,
 //                        left in HBM in the layout of the LDS topology
-//   k_clip_pairs(_big)  A7+A8+A11  Mesh of those pairs: plane loop on the reduced solid, label islands,
-//                        park the result in the arena                          (Src/Surtr.cpp:1470-1504, Src/Poly.cpp:265-500)
+//   k_clip_pairs(_big, _half)  A7+A8+A11  Mesh of those pairs: plane loop on the reduced solid, label islands,
+//                        park the result in the arena                          (Src/Surtr.cpp:1470-1504, Src/Poly.cpp:265-500);
+//                        three LDS topology sizes (regular, double for large bands, half for light pairs of small pieces)
 //   k_frag_table    A11  cell-major fragment table                             (Src/Surtr.cpp:2133-2146)
 //   k_refit         A12  limit-4 hull normals + k-DOP slabs + clip Convex      (Src/Surtr.cpp:1449-1455)
 //   k_faces         A9+A10  ExtractFaces + EarClipping of every Mesh           (Src/Poly.cpp:89-126, 764-913)
