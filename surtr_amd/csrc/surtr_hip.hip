@@ -650,7 +650,8 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                                                     const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                     uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                     ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
-                                                    const uint2* __restrict__ pair_list, uint32_t* __restrict__ porder)
+                                                    const uint2* __restrict__ pair_list, uint32_t* __restrict__ porder,
+                                                    const uint32_t* __restrict__ cell_order)
 {
     __shared__ Shared sh;
     __shared__ LdsTopoSmall L;
@@ -662,8 +663,11 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         __syncthreads();
         if (tid == 0) sh.misc[7] = atomicAdd(&A.cursors[8], 1u);
         __syncthreads();
-        const uint32_t p = sh.misc[7];
+        uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
+        // cells with many planes first (cell_order: the event's cells by plane count, descending): the clip of a Convex costs
+        // about one step per plane, and the last tasks of the queue set the length of the kernel
+        if (cell_order != nullptr) p = (cell_order[p / P.n] - cell_begin) * P.n + p % P.n;
         const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         PairRec rec;
@@ -1999,6 +2003,7 @@ struct surtr_ctx
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
     uint32_t n_cells = 0, n_faces = 0;
+    uint32_t* d_cell_order = nullptr; uint32_t cell_order_begin = 0, cell_order_count = 0;      // k_clip_convex: cells of the last range by plane count
     float* d_v012 = nullptr; float4* d_planes = nullptr; uint32_t* d_plane_off = nullptr;
     std::vector<uint32_t> h_plane_off;
     bool planes_ready = false;
@@ -2118,6 +2123,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->d_cell_order);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
 #ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -2391,7 +2397,7 @@ int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_
     HIPCHK(hipMemcpy(ctx->d_v012, v012, (size_t)nf * 36, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_plane_off, face_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
     ctx->h_plane_off.assign(face_off, face_off + n_cells + 1);
-    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = false;
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = false; ctx->cell_order_count = 0;
     return SURTR_OK;
 }
 
@@ -2423,7 +2429,7 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
     HIPCHK(hipMemcpy(ctx->d_planes, planes, (size_t)nf * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_plane_off, plane_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
     ctx->h_plane_off.assign(plane_off, plane_off + n_cells + 1);
-    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = true;
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = true; ctx->cell_order_count = 0;
     return SURTR_OK;
 }
 
@@ -2583,10 +2589,27 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad, ctx->d_mperm, ctx->d_mpos_s, ctx->d_mrad_s, ctx->d_mbsph, ctx->d_mbo,
              ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->d_cperm, ctx->d_cpos_s, ctx->d_crad_s, ctx->d_cbsph, ctx->d_cbo, ctx->n_pieces};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
+    const uint32_t* d_cell_order = nullptr;
+    if (!d_pair_list && n_pairs && ctx->n_pieces && n_pairs % ctx->n_pieces == 0 && !getenv("SURTR_NO_CELL_ORDER"))
+    {
+        const uint32_t nc = n_pairs / ctx->n_pieces;
+        if (!ctx->d_cell_order || ctx->cell_order_begin != cell_begin || ctx->cell_order_count != nc)
+        {
+            std::vector<uint32_t> ord(nc);
+            for (uint32_t i = 0; i < nc; ++i) ord[i] = cell_begin + i;
+            const std::vector<uint32_t>& po = ctx->h_plane_off;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return po[a + 1] - po[a] > po[b + 1] - po[b]; });
+            free_dev(ctx->d_cell_order); ctx->d_cell_order = nullptr;
+            HIPCHK(hipMalloc((void**)&ctx->d_cell_order, (size_t)nc * 4));
+            HIPCHK(hipMemcpy(ctx->d_cell_order, ord.data(), (size_t)nc * 4, hipMemcpyHostToDevice));
+            ctx->cell_order_begin = cell_begin; ctx->cell_order_count = nc;
+        }
+        d_cell_order = ctx->d_cell_order;
+    }
     PROF_BEGIN(6);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order);
+                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_cell_order);
     PROF_END(6);
     PROF_BEGIN(7);
     if (n_pairs)
