@@ -41,6 +41,10 @@ struct PairRec
     // reduced Mesh left in HBM by k_prep_pairs: img_fmt = IMG_*, offset in 16-byte units, vertices, ring entries,
     // position slots reserved (>= the capacity of the topology that will clip it: positions are then used in place)
     uint32_t img_fmt, img_off, img_n, img_h, img_pc;
+    // 1: the clip of the Convex ended in an inconsistent solid (degenerate input, where the reference produces an invalid
+    // polyhedron and carries on).  The pair goes on like the reference's: if nothing is left of the Mesh it yields no fragment
+    // and the event is fine; a fragment that would carry the invalid Convex fails the event with SURTR_E_TOPOLOGY.
+    uint32_t cv_bad;
 };
 
 enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                                                     uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                     ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
                                                     const uint2* __restrict__ pair_list, uint32_t* __restrict__ porder,
-                                                    const uint32_t* __restrict__ cell_order)
+                                                    const uint32_t* __restrict__ pair_order)
 {
     __shared__ Shared sh;
     __shared__ LdsTopoSmall L;
@@ -665,9 +669,9 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         __syncthreads();
         uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
-        // cells with many planes first (cell_order: the event's cells by plane count, descending): the clip of a Convex costs
-        // about one step per plane, and the last tasks of the queue set the length of the kernel
-        if (cell_order != nullptr) p = (cell_order[p / P.n] - cell_begin) * P.n + p % P.n;
+        // pairs of cells with many planes first (pair_order: the event's pairs by plane count of their cell, descending): the
+        // clip of a Convex costs about one step per plane, and the last tasks of the queue set the length of the kernel
+        if (pair_order != nullptr) p = pair_order[p];
         const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         PairRec rec;
@@ -698,6 +702,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                 __syncthreads();
             }
         }
+        if (err == SURTR_E_TOPOLOGY) { rec.cv_bad = 1; rec.cv_off = 0; rec.cv_n = 1; rec.ch_off = 0; rec.ch_n = 0; err = 0; }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
         if (rec.cv_n != 0 && porder != nullptr)
@@ -922,8 +927,9 @@ __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t p
         if (T.nLive == 0) return 0;
         return park_mesh_islands(T, sh, A, rec);
     };
-    const int err = clip_global(min, F, S, sh, consume);
+    int err = clip_global(min, F, S, sh, consume);
     __syncthreads();
+    if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;
     if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (threadIdx.x == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
     if (threadIdx.x == 0) pairs[p] = rec;
     return err;
@@ -1014,6 +1020,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
                 continue;
             }
         }
+        if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
@@ -2003,7 +2010,8 @@ struct surtr_ctx
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
     uint32_t n_cells = 0, n_faces = 0;
-    uint32_t* d_cell_order = nullptr; uint32_t cell_order_begin = 0, cell_order_count = 0;      // k_clip_convex: cells of the last range by plane count
+    uint32_t* d_pair_order = nullptr; uint32_t pair_order_begin = 0, pair_order_count = 0, cap_pair_order = 0;   // k_clip_convex: pairs by plane count
+    bool pair_order_is_list = false;
     float* d_v012 = nullptr; float4* d_planes = nullptr; uint32_t* d_plane_off = nullptr;
     std::vector<uint32_t> h_plane_off;
     bool planes_ready = false;
@@ -2123,7 +2131,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
-    free_dev(ctx->d_cell_order);
+    free_dev(ctx->d_pair_order);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
 #ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -2366,7 +2374,7 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const f
                     cvmax, chmax, cv, chh);
     if (rc) return rc;
     ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
-    ctx->tot_mv = tv; ctx->tot_mh = th;
+    ctx->tot_mv = tv; ctx->tot_mh = th; ctx->pair_order_count = 0;
     {
         uint32_t small = 0;
         for (uint32_t i = 0; i < n; ++i)
@@ -2397,7 +2405,7 @@ int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_
     HIPCHK(hipMemcpy(ctx->d_v012, v012, (size_t)nf * 36, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_plane_off, face_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
     ctx->h_plane_off.assign(face_off, face_off + n_cells + 1);
-    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = false; ctx->cell_order_count = 0;
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = false; ctx->pair_order_count = 0;
     return SURTR_OK;
 }
 
@@ -2429,7 +2437,7 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
     HIPCHK(hipMemcpy(ctx->d_planes, planes, (size_t)nf * 16, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(ctx->d_plane_off, plane_off, (size_t)(n_cells + 1) * 4, hipMemcpyHostToDevice));
     ctx->h_plane_off.assign(plane_off, plane_off + n_cells + 1);
-    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = true; ctx->cell_order_count = 0;
+    ctx->n_cells = n_cells; ctx->n_faces = nf; ctx->planes_ready = true; ctx->pair_order_count = 0;
     return SURTR_OK;
 }
 
@@ -2518,9 +2526,11 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
 
 static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
 {
-    // Result sizes are data dependent; the default reserves the whole input once per 8 pairs plus slack.
-    uint64_t av = ctx->user_av ? ctx->user_av : std::max<uint64_t>((uint64_t)ctx->vmax * 8 + (uint64_t)n_pairs * 256, 1u << 16);
-    uint64_t ah = ctx->user_ah ? ctx->user_ah : std::max<uint64_t>((uint64_t)ctx->hmax * 8 + (uint64_t)n_pairs * 1024, 1u << 18);
+    // Result sizes are data dependent.  Cells partition space, so the Mesh fragments of an event add up to the pieces plus
+    // their cut points: the default reserves three times all pieces (at least eight times the largest one) plus slack per pair
+    // (Convex results); surtr_set_arena overrides it, SURTR_E_CAPACITY reports a default that was too small.
+    uint64_t av = ctx->user_av ? ctx->user_av : std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctx->vmax * 8, ctx->tot_mv * 3) + (uint64_t)n_pairs * 256, 1u << 16);
+    uint64_t ah = ctx->user_ah ? ctx->user_ah : std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctx->hmax * 8, ctx->tot_mh * 3) + (uint64_t)n_pairs * 1024, 1u << 18);
     uint64_t ai = ctx->user_ai ? ctx->user_ai : ah * 2;
     av = std::min<uint64_t>(av, 0xFFFFFFF0ull); ah = std::min<uint64_t>(ah, 0xFFFFFFF0ull); ai = std::min<uint64_t>(ai, 0xFFFFFFF0ull);
     const uint32_t capIsl = (uint32_t)std::min<uint64_t>((uint64_t)n_pairs * 4 + 1024, 0x7FFFFFFFull);
@@ -2558,6 +2568,18 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
     return SURTR_OK;
 }
 
+static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pairs)
+{
+    if (ctx->cap_pair_order < n_pairs)
+    {
+        free_dev(ctx->d_pair_order); ctx->d_pair_order = nullptr; ctx->cap_pair_order = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_pair_order, (size_t)n_pairs * 4));
+        ctx->cap_pair_order = n_pairs;
+    }
+    HIPCHK(hipMemcpy(ctx->d_pair_order, ord, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+    return SURTR_OK;
+}
+
 static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
     (void)hipSetDevice(ctx->device);
@@ -2589,27 +2611,29 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad, ctx->d_mperm, ctx->d_mpos_s, ctx->d_mrad_s, ctx->d_mbsph, ctx->d_mbo,
              ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->d_cperm, ctx->d_cpos_s, ctx->d_crad_s, ctx->d_cbsph, ctx->d_cbo, ctx->n_pieces};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
-    const uint32_t* d_cell_order = nullptr;
-    if (!d_pair_list && n_pairs && ctx->n_pieces && n_pairs % ctx->n_pieces == 0 && !getenv("SURTR_NO_CELL_ORDER"))
+    const uint32_t* d_pair_order = nullptr;
+    if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it
+    else if (!d_pair_list && n_pairs && ctx->n_pieces && n_pairs % ctx->n_pieces == 0 && !getenv("SURTR_NO_CELL_ORDER"))
     {
-        const uint32_t nc = n_pairs / ctx->n_pieces;
-        if (!ctx->d_cell_order || ctx->cell_order_begin != cell_begin || ctx->cell_order_count != nc)
+        const uint32_t np = ctx->n_pieces, nc = n_pairs / np;
+        if (ctx->pair_order_is_list || ctx->pair_order_begin != cell_begin || ctx->pair_order_count != n_pairs)
         {
-            std::vector<uint32_t> ord(nc);
-            for (uint32_t i = 0; i < nc; ++i) ord[i] = cell_begin + i;
+            std::vector<uint32_t> cells(nc), ord((size_t)n_pairs);
+            for (uint32_t i = 0; i < nc; ++i) cells[i] = i;
             const std::vector<uint32_t>& po = ctx->h_plane_off;
-            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return po[a + 1] - po[a] > po[b + 1] - po[b]; });
-            free_dev(ctx->d_cell_order); ctx->d_cell_order = nullptr;
-            HIPCHK(hipMalloc((void**)&ctx->d_cell_order, (size_t)nc * 4));
-            HIPCHK(hipMemcpy(ctx->d_cell_order, ord.data(), (size_t)nc * 4, hipMemcpyHostToDevice));
-            ctx->cell_order_begin = cell_begin; ctx->cell_order_count = nc;
+            std::stable_sort(cells.begin(), cells.end(), [&](uint32_t a, uint32_t b) {
+                return po[cell_begin + a + 1] - po[cell_begin + a] > po[cell_begin + b + 1] - po[cell_begin + b]; });
+            for (uint32_t i = 0; i < nc; ++i) for (uint32_t q = 0; q < np; ++q) ord[(size_t)i * np + q] = cells[i] * np + q;
+            int rc2 = upload_pair_order(ctx, ord.data(), n_pairs);
+            if (rc2) return rc2;
+            ctx->pair_order_is_list = false; ctx->pair_order_begin = cell_begin; ctx->pair_order_count = n_pairs;
         }
-        d_cell_order = ctx->d_cell_order;
+        d_pair_order = ctx->d_pair_order;
     }
     PROF_BEGIN(6);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_cell_order);
+                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order);
     PROF_END(6);
     PROF_BEGIN(7);
     if (n_pairs)
@@ -2727,6 +2751,20 @@ int surtr_fracture_pairs_async(surtr_ctx* ctx, uint32_t n_pairs, const uint32_t*
     }
     if (n_pairs) HIPCHK(hipMemcpyAsync(ctx->d_pair_list, list.data(), (size_t)n_pairs * sizeof(uint2), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));     // `list` is a stack-owned staging buffer
+    ctx->pair_order_count = 0;
+    if (n_pairs && !getenv("SURTR_NO_CELL_ORDER"))
+    {
+        // queue order of k_clip_convex: pairs by plane count of their cell, descending (counting sort, stable)
+        const std::vector<uint32_t>& po = ctx->h_plane_off;
+        uint32_t start[SURTR_MAXF + 2] = {0};
+        for (uint32_t i = 0; i < n_pairs; ++i) ++start[SURTR_MAXF - (po[pair_cell[i] + 1] - po[pair_cell[i]]) + 1];
+        for (uint32_t k = 1; k <= SURTR_MAXF + 1; ++k) start[k] += start[k - 1];
+        std::vector<uint32_t> ord(n_pairs);
+        for (uint32_t i = 0; i < n_pairs; ++i) ord[start[SURTR_MAXF - (po[pair_cell[i] + 1] - po[pair_cell[i]])]++] = i;
+        int rc2 = upload_pair_order(ctx, ord.data(), n_pairs);
+        if (rc2) return rc2;
+        ctx->pair_order_is_list = true; ctx->pair_order_count = n_pairs;
+    }
     return launch_event(ctx, 0, n_pairs, ctx->d_pair_list, nullptr, flags);
 }
 
