@@ -8,7 +8,7 @@ import numpy as np
 from oracle import oracle as O
 from surtr_amd import engine as E
 from helpers import assert_event_equal
-from test_refracture import _refracture
+from test_refracture import _refracture, _links_symmetric
 from surtr_amd import scenes as S, meshgen as G
 
 
@@ -22,7 +22,8 @@ def reference_result_is_invalid(n_first, n_second, nu, nv):
     eng.fracture_event(0, n_first, flags=1)
     meshes, convexes = S.fragments_as_pieces(eng.download())
     eng.close()
-    keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4]
+    keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4
+            and _links_symmetric(m) and _links_symmetric(convexes[i])]
     meshes, convexes = [meshes[i] for i in keep], [convexes[i] for i in keep]
     rs = S.refracture_scene(meshes, convexes, n_second)
     for p in range(len(meshes)):

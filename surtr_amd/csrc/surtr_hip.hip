@@ -1554,12 +1554,21 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         }
         __syncthreads();
         STAMP(60);
-        const bool irregular = sh.flagBad != 0;
+        bool irregular = sh.flagBad != 0;
         uint32_t nfaces = 0, lensum = 0;
         int32_t* faceLo = nxB; int32_t* faceLen = keyB;
         bool serial_extract = false;
         int32_t* kc = keyA;           // per half-edge: the smallest half-edge whose face walk visits it (== itself: a face starts here)
-        const bool staged = irregular && n <= FL_V && H <= FL_H;
+        bool staged = false, failed = false;
+        // Two attempts at most: a fragment that looked regular may turn out to have a half-edge loop that passes through
+        // a vertex twice (coincident vertices of a degenerate fragment; no ring lists a neighbour twice).  The reference
+        // closes a face when its walk is back at the start VERTEX (:100-118), so such a loop is several faces; only the
+        // literal path below reproduces that.  The loops then cover fewer than H half-edges: redo as irregular.
+        for (int attempt = 0; attempt < 2; ++attempt)
+        {
+        nfaces = 0; lensum = 0; faceLo = nxB; faceLen = keyB; serial_extract = false; kc = keyA;
+        staged = irregular && n <= FL_V && H <= FL_H;
+        bool pinched = false;
         if (irregular)
         {
             // Sliver fragment (a ring lists a neighbour twice): the reference keys its visited set by the (vertex, neighbour)
@@ -1676,8 +1685,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 return make_uint2(1u, len);
             };
             scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
-            if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
-            const uint32_t nb = (H + SURTR_LANES - 1u) >> SURTR_LSH;
+            if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); failed = true; break; }
+            if (!irregular && lensum != H) pinched = true;
+            const uint32_t nb = pinched ? 0u : (H + SURTR_LANES - 1u) >> SURTR_LSH;
             for (uint32_t b = wave_id(); b < nb; b += group_waves())
             {
                 const uint32_t e = (b << SURTR_LSH) + lane_id();
@@ -1751,9 +1761,15 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             nfaces = sh.misc[0]; lensum = sh.misc[1];
             const bool bad = sh.misc[2] != 0;
             __syncthreads();
-            if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); continue; }
+            if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); failed = true; break; }
         }
         __syncthreads();
+        if (!pinched) break;
+        irregular = true;
+        if (tid == 0) sh.flagBad = 0;
+        __syncthreads();
+        }   // attempts
+        if (failed) continue;
         STAMP(62);
         // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
         //    room for 3*len indices at 3*lo

@@ -348,3 +348,22 @@ def test_sliver_piece_whose_convex_clip_is_invalid_in_the_reference(emul_engine,
     c = eng.fracture_event(0, 1, flags=3)
     assert c.status == 0 and c.n_frag == 0
     eng.close()
+
+
+def test_fragment_with_a_face_loop_through_one_vertex_twice(emul_engine, oracle):
+    """Found by scripts/fuzz_refracture_gpu.py: a degenerate second-level fragment (coincident vertices) whose half-edge loop
+    passes through a vertex twice although no ring lists a neighbour twice.  The reference closes a face when its walk is back
+    at the start vertex (Src/Poly.cpp:100-118), so that loop is two faces (a triangle and a pentagon here); k_faces used to
+    emit one and drop four triangles.  Such fragments are now redone by the literal path."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pinched_face_fragment.npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    fo = d["fo"].astype(np.uint32)
+    eng = emul_engine.Engine(0)
+    eng.upload_pieces([mesh], [conv]); eng.upload_planes(fo, d["planes"])
+    c = eng.fracture_event(0, len(fo) - 1, flags=3)
+    got = eng.download()
+    eng.close()
+    ref = oracle.event([mesh], [conv], fo, d["planes"], refit=True, render=True, threads=2)
+    assert c.status == 0
+    assert_event_equal(got, ref)

@@ -263,3 +263,20 @@ def test_prepare_fracture_end_to_end_gpu(gpu_engine, oracle):
     assert c.status == 0 and c.n_frag >= 48
     assert_event_equal(got, ref)
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["pinched_face_fragment", "degenerate_sliver_convex"])
+def test_degenerate_fragments_found_by_the_refracture_fuzz(gpu_engine, oracle, name):
+    """tests/test_emul_parity.py explains the two fixtures; same checks on the GPU."""
+    d = np.load(os.path.join(HERE, name + ".npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    fo = d["fo"].astype(np.uint32) if "fo" in d.files else np.uint32([0, d["planes"].shape[0]])
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([mesh], [conv]); eng.upload_planes(fo, d["planes"])
+    c = eng.fracture_event(0, len(fo) - 1, flags=3)
+    got = eng.download()
+    eng.close()
+    ref = oracle.event([mesh], [conv], fo, d["planes"], refit=True, render=True, threads=2)
+    assert c.status == 0
+    assert_event_equal(got, ref)

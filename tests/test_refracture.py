@@ -6,6 +6,20 @@ from helpers import assert_event_equal
 from surtr_amd import meshgen, scenes
 
 
+def _links_symmetric(solid):
+    """The reference's input check (Src/Poly.cpp:253-260) as surtr_upload_pieces applies it: degenerate clips can leave a
+    fragment with a one-way link, a link to itself or a vertex of degree two; such a fragment is no valid piece (the
+    engine's upload refuses it with SURTR_E_TOPOLOGY)."""
+    off, nbr = solid["off"].astype(np.int64), solid["nbr"]
+    V = off.shape[0] - 1
+    if nbr.size and (int(nbr.min()) < 0 or int(nbr.max()) >= V):
+        return False
+    if V == 0 or int(np.diff(off).min()) < 3:
+        return False
+    rings = [set(nbr[off[v]:off[v + 1]].tolist()) for v in range(V)]
+    return all(u != v and v in rings[u] for v in range(V) for u in rings[v])
+
+
 def _refracture(engine_mod, oracle, n_first, n_second, nu, nv):
     sc = scenes.make_scene(*meshgen.bumpy_torus(nu, nv), n_first)
     eng = engine_mod.Engine(0)
@@ -17,7 +31,8 @@ def _refracture(engine_mod, oracle, n_first, n_second, nu, nv):
     meshes, convexes = scenes.fragments_as_pieces(first)
     # fragments with sliver faces are valid inputs too, but a ring that lists a neighbour twice has a degree-2
     # neighbourhood the upload check rejects as in the reference's assertion; keep the regular ones
-    keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4]
+    keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4
+            and _links_symmetric(m) and _links_symmetric(convexes[i])]
     meshes, convexes = [meshes[i] for i in keep], [convexes[i] for i in keep]
     rs = scenes.refracture_scene(meshes, convexes, n_second)
     eng.upload_pieces(meshes, convexes)
