@@ -103,6 +103,9 @@ int surtr_kernel_times(surtr_ctx* ctx, float ms[16]);
  * class c, [48+c] pairs of pre-pass class c, [64+c] pairs of class c handed to k_clip_pairs_half, [64] pairs that outgrew
  * its half-size LDS topology and were redone by k_clip_pairs. */
 int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128]);
+/* Diagnostic: the status of every pair of the last event (0, or the SURTR_E_* code that pair raised), in pair order
+ * (cell-major for surtr_fracture_event, list order for surtr_fracture_pairs).  Works after an event that failed. */
+int surtr_pair_status(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* status);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Replaces compound.PieceVec (Inc/Surtr.h:113-134): n pieces, each a (Convex, Mesh)

@@ -2910,6 +2910,18 @@ int surtr_kernel_times(surtr_ctx* ctx, float ms[16])
     return SURTR_OK;
 }
 
+int surtr_pair_status(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* status)
+{
+    if (!ctx || !status) return SURTR_E_INVALID;
+    if (!ctx->have_event || n_pairs > ctx->cap_pairs) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<PairRec> recs(n_pairs);
+    if (n_pairs) HIPCHK(hipMemcpy(recs.data(), ctx->d_pairs, (size_t)n_pairs * sizeof(PairRec), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_pairs; ++i) status[i] = recs[i].status;
+    return SURTR_OK;
+}
+
 int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128])
 {
     if (!ctx || !out) return SURTR_E_INVALID;

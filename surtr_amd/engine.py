@@ -136,6 +136,12 @@ class Engine:
         names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
+    def pair_status(self, n_pairs):
+        """Status per pair of the last event (include/surtr_hip.h: surtr_pair_status)."""
+        out = np.zeros(n_pairs, dtype=np.uint32)
+        self._ck(lib().surtr_pair_status(self._h, ctypes.c_uint32(n_pairs), _p(out)))
+        return out
+
     def queue_stats(self):
         """Device-side counters of the last event (include/surtr_hip.h: surtr_queue_stats)."""
         out = (ctypes.c_uint32 * 128)()
