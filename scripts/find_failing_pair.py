@@ -20,7 +20,7 @@ rs = scenes.refracture_scene(meshes, convexes, n_second)
 eng.upload_pieces(meshes, convexes); eng.upload_pattern(rs["face_off"], rs["v012"]); eng.place_cells_groups(rs["group_cell_off"], rs["scales"], rs["shifts"])
 npairs = rs["pair_cell"].shape[0]
 try:
-    c = eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=3); print("event ok, frags", c.n_frag)
+    c = eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=int(os.environ.get("SURTR_FLAGS", "3"))); print("event ok, frags", c.n_frag)
 except E.SurtrError as ex:
     print("event error", ex.code)
 st = eng.pair_status(npairs)
