@@ -35,3 +35,26 @@ for i in bad[:4]:
     np.savez(os.path.join(ROOT, "gpurun_out", "failing_pair_%d.npz" % i), mesh_pos=meshes[p]["pos"], mesh_off=meshes[p]["off"], mesh_nbr=meshes[p]["nbr"],
              conv_pos=convexes[p]["pos"], conv_off=convexes[p]["off"], conv_nbr=convexes[p]["nbr"], planes=planes)
 eng.close()
+if os.environ.get("SURTR_COMPARE"):
+    # compare the clip results (no render) of the whole event with the oracle, piece by piece
+    from helpers import assert_event_equal
+    eng = E.Engine(0)
+    eng.upload_pieces(meshes, convexes); eng.upload_pattern(rs["face_off"], rs["v012"]); eng.place_cells_groups(rs["group_cell_off"], rs["scales"], rs["shifts"])
+    eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=1); got = eng.download(); eng.close()
+    parts = []
+    for p in range(len(meshes)):
+        a, b = int(rs["group_cell_off"][p]), int(rs["group_cell_off"][p + 1])
+        f0, f1 = int(rs["face_off"][a]), int(rs["face_off"][b])
+        planes = O.place_cells(rs["v012"][f0:f1], rs["scales"][p], rs["shifts"][p])
+        ev = O.event([meshes[p]], [convexes[p]], rs["face_off"][a:b + 1] - rs["face_off"][a], planes, refit=True, render=False, threads=4)
+        ev["frag_ids"] = ev["frag_ids"] + np.array([a, p, 0], np.int32)
+        parts.append(ev)
+    ref = E.merge_fragments(parts)
+    try:
+        assert_event_equal(got, ref, render=False); print("clip + refit results equal the oracle's (%d fragments)" % ref["frag_ids"].shape[0])
+    except AssertionError as ex:
+        print("clip results DIFFER:", str(ex)[:100])
+    f = 934
+    a, b = int(ref["mesh_vert_off"][f]), int(ref["mesh_vert_off"][f + 1]); no = ref["mesh_nbr_off"]
+    np.savez(os.path.join(ROOT, "gpurun_out", "fragment_934.npz"), pos=ref["mesh_pos"][a:b], off=(no[a:b + 1] - no[a]).astype(np.uint32), nbr=ref["mesh_nbr"][int(no[a]):int(no[b])])
+    print("fragment 934: V", b - a, "H", int(no[b] - no[a]))

@@ -41,6 +41,33 @@ def reference_result_is_invalid(n_first, n_second, nu, nv):
                 rings = [set(r["nbr"][r["off"][v]:r["off"][v + 1]].tolist()) for v in range(V)]
                 if any(v not in rings[u] for v in range(V) for u in rings[v]):
                     return True
+    # ... or a fragment on which the reference's ExtractFaces (Src/Poly.cpp:89-126, `while (cur != i)`) never ends: a walk
+    # that is not back at its start vertex after H steps has repeated a (previous, current) state
+    for p in range(len(meshes)):
+        a, b = int(rs["group_cell_off"][p]), int(rs["group_cell_off"][p + 1])
+        f0, f1 = int(rs["face_off"][a]), int(rs["face_off"][b])
+        planes = O.place_cells(rs["v012"][f0:f1], rs["scales"][p], rs["shifts"][p])
+        ev = O.event([meshes[p]], [convexes[p]], rs["face_off"][a:b + 1] - rs["face_off"][a], planes, refit=False, render=False, threads=4)
+        vo, no, nb = ev["mesh_vert_off"], ev["mesh_nbr_off"], ev["mesh_nbr"]
+        for f in range(len(vo) - 1):
+            v0, v1 = int(vo[f]), int(vo[f + 1])
+            ring = [nb[int(no[v]):int(no[v + 1])].tolist() for v in range(v0, v1)]
+            H = sum(len(r) for r in ring)
+            seen = set()
+            for i in range(v1 - v0):
+                for adj in ring[i]:
+                    if (i, adj) in seen:
+                        continue
+                    prev, cur, steps = i, adj, 0
+                    while cur != i:
+                        seen.add((prev, cur))
+                        r = ring[cur]
+                        k = r.index(prev) if prev in r else len(r)
+                        prev, cur = cur, (r[-1] if k == 0 or k == len(r) else r[k - 1])
+                        steps += 1
+                        if steps > H:
+                            return True
+                    seen.add((prev, cur))
     return False
 
 
@@ -62,7 +89,7 @@ def main():
         except E.SurtrError as e:
             if e.code == E.E_TOPOLOGY and reference_result_is_invalid(n_first, n_second, nu, nv):
                 refused += 1
-                print("case %d torus %dx%d first %d second %d: refused (SURTR_E_TOPOLOGY); the reference's clip of one of the pieces is not a solid  (%.0fs)" % (
+                print("case %d torus %dx%d first %d second %d: refused (SURTR_E_TOPOLOGY); the reference's clip of one of the pieces is not a solid, or its ExtractFaces would not end  (%.0fs)" % (
                     case, nu, nv, n_first, n_second, time.time() - t0), flush=True)
             else:
                 bad += 1
