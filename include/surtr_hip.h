@@ -60,6 +60,8 @@ typedef struct surtr_counts {
     uint32_t n_idx;        /* triangle indices (render buffers) */
     uint32_t n_pairs;      /* (cell, piece) pairs processed */
     uint32_t status;       /* device-side status word, SURTR_OK or an error code */
+    uint32_t n_failed;     /* fragments that got no triangles because Poly::ExtractFaces does not terminate on them
+                            * (Src/Poly.cpp:100-118); frag_status names them.  The event itself is SURTR_OK. */
 } surtr_counts;
 
 /* Host-side view used by surtr_event_download: every pointer may be NULL to
@@ -77,6 +79,7 @@ typedef struct surtr_fragments {
     float* vnc;                 /* 9*mesh_verts: VertexNormalColor (Inc/Mesh.h:4-13) of every Mesh vertex */
     uint32_t* idx_off;          /* n_frag+1 */
     uint32_t* idx;              /* n_idx, fragment-local vertex indices (Src/Poly.cpp:708-713) */
+    uint32_t* frag_status;      /* n_frag: SURTR_OK, or SURTR_E_TOPOLOGY for a fragment without triangles (see n_failed) */
 } surtr_fragments;
 
 /* ---- life cycle -------------------------------------------------------- */
@@ -173,6 +176,50 @@ int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const u
                           uint32_t n_planes, const float* planes,
                           uint32_t* out_nv, uint32_t* out_nh, float* out_pos, uint32_t* out_nbr_off, int32_t* out_nbr);
 
+/* The three per-Piece tasks for ONE solid (what m_refittingTask and m_initCompoundTask do to a Piece, Inc/Surtr.h:270-271),
+ * run by the same kernels as the event.  They use the event arena: the fragments of the last event are gone afterwards.
+ *
+ * m_refittingTask (Src/Surtr.cpp:1449-1455): ConvexHull(mesh points, min(n, 4)) -> Kdop::Calc(mesh) ->
+ * ClipWithPolyhedron(convex).  Count-then-fill like surtr_clip_polyhedron. */
+int surtr_refit_solid(surtr_ctx* ctx, uint32_t mesh_nv, const float* mesh_pos, const uint32_t* mesh_nbr_off, const int32_t* mesh_nbr,
+                      uint32_t conv_nv, const float* conv_pos, const uint32_t* conv_nbr_off, const int32_t* conv_nbr,
+                      uint32_t* out_nv, uint32_t* out_nh, float* out_pos, uint32_t* out_nbr_off, int32_t* out_nbr);
+/* Poly::ExtractFaces (Src/Poly.cpp:89-126): face loops in visiting order, face f = face_idx[face_off[f] .. face_off[f+1]).
+ * Count-then-fill: NULL arrays return n_faces / n_face_idx only.  SURTR_E_TOPOLOGY where the reference's walk never ends. */
+int surtr_extract_faces(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr,
+                        uint32_t* n_faces, uint32_t* n_face_idx, uint32_t* face_off, int32_t* face_idx);
+/* Poly::ExtractFaces + Poly::RenderPolyhedron (Src/Poly.cpp:681-714): vnc = 9 floats per vertex (VertexNormalColor with
+ * `color`, NULL = 0.25), idx = triangle indices; is_convex selects the fan (:696-706) or EarClipping (:707-713).
+ * Count-then-fill: idx NULL returns n_idx. */
+int surtr_triangulate(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* nbr_off, const int32_t* nbr, int is_convex,
+                      const float color[3], float* vnc, uint32_t* n_idx, uint32_t* idx);
+
+/* Presents n host pieces as the fragments of an event (fragment k = Mesh k + Convex k, ids = frag_ids[3k..] or
+ * (k, 0, 0) when NULL), so that surtr_event_refit / surtr_event_triangulate / surtr_event_download /
+ * surtr_pieces_from_event work on solids that did not come out of surtr_fracture_event. */
+int surtr_load_fragments(surtr_ctx* ctx, uint32_t n,
+                         const uint32_t* mesh_vert_off, const float* mesh_pos, const uint32_t* mesh_nbr_off, const int32_t* mesh_nbr,
+                         const uint32_t* conv_vert_off, const float* conv_pos, const uint32_t* conv_nbr_off, const int32_t* conv_nbr,
+                         const int32_t* frag_ids);
+/* m_initCompoundTask's triangulation (Src/Surtr.cpp:1436-1447) of every Mesh of the current fragments; is_convex as above. */
+int surtr_event_triangulate(surtr_ctx* ctx, int is_convex);
+
+/* ---- device-resident pieces -------------------------------------------- */
+/* Poly::Transform (Src/Poly.cpp:580-585) of piece i's Convex and Mesh by world[16*i .. 16*i+16) -- the row-major XMMATRIX of
+ * m_structuredBufferData[i].WorldMatrix, transposed before use as the reference does -- on the resident copies
+ * (ExecuteFractureRoutine's pre-transform, Src/Surtr.cpp:1846-1851).  No host round trip. */
+int surtr_transform_pieces(surtr_ctx* ctx, uint32_t n_pieces, const float* world);
+/* The fragments of the last event become the resident pieces (recursive refracture without leaving HBM): fragment k is kept
+ * when keep == NULL or keep[k] != 0; kept fragments become pieces 0, 1, ... in fragment order.  n_pieces returns their number. */
+int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_pieces);
+/* Reads resident piece `piece` back (set 0 = Mesh, 1 = Convex): count-then-fill like surtr_clip_polyhedron.  For tests and for
+ * Poly::Transform of a single host polyhedron; the event path never needs it. */
+int surtr_download_piece(surtr_ctx* ctx, uint32_t piece, int set, uint32_t* out_nv, uint32_t* out_nh, float* out_pos,
+                         uint32_t* out_nbr_off, int32_t* out_nbr);
+/* Host time of the last surtr_upload_pieces / surtr_pieces_from_event / surtr_transform_pieces call, in milliseconds,
+ * and how many device allocations it made (0 in steady state: the piece buffers are pooled). */
+int surtr_upload_stats(surtr_ctx* ctx, float* ms, uint32_t* n_alloc);
+
 /* ---- host-side helpers of the harness (no GPU needed) ------------------ */
 /* Poly::ExtractNeighborFromMesh, Src/Poly.cpp:128-263: welded triangle soup ->
  * neighbour rings.  nbr must hold 2*3*n_tris entries at most; returns
@@ -193,6 +240,13 @@ int surtr_hull_normals(uint32_t n, const float* points, uint32_t limit, uint32_t
  * plane then the Max plane (the order ClipWithPolyhedron clips in, :166-179); planes holds 8 floats per normal. */
 int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const float* normals, double max_axis_scale,
                           float plane_gap_inv, float* planes);
+
+/* Plane(p0, p1, p2) as PolygonFace::ConstructFacePlane builds it (Src/VMACH.cpp:302-310; normalised, SimpleMath.inl:2773-2780). */
+int surtr_plane_from_points(const float p0[3], const float p1[3], const float p2[3], float plane[4]);
+
+/* Kdop::KdopContainer::Calc(const Poly::Polyhedron&) (Src/Kdop.cpp:92-115): Min plane then Max plane per normal through the
+ * first extreme vertices, not normalised, no gap (the refit variant; k_refit does the same per fragment on the device). */
+int surtr_kdop_planes(uint32_t n, const float* points, uint32_t k, const float* normals, float* planes);
 
 /* Poly::Moments (Src/Poly.cpp:55-87): signed volume and centroid of a closed solid (host; the test invariant of
  * fragment volumes partition the input). */

@@ -504,6 +504,52 @@ int surtr_kdop_ach_planes(uint32_t n, const float* points, uint32_t k, const flo
     return SURTR_OK;
 }
 
+// Plane(p0, p1, p2) of SimpleMath (SimpleMath.inl:2773-2780, XMPlaneFromPoints): normal = normalize((p0-p1) x (p0-p2)),
+// d = -dot(normal, p0) -- the arithmetic of k_place_cells, for PolygonFace::ConstructFacePlane (Src/VMACH.cpp:302-310) in the
+// C++ host layer.
+int surtr_plane_from_points(const float p0[3], const float p1[3], const float p2[3], float plane[4])
+{
+    if (!p0 || !p1 || !p2 || !plane) return SURTR_E_INVALID;
+    const float ax = p0[0] - p1[0], ay = p0[1] - p1[1], az = p0[2] - p1[2];
+    const float bx = p0[0] - p2[0], by = p0[1] - p2[1], bz = p0[2] - p2[2];
+    float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    float t = nx * nx + ny * ny; t = t + nz * nz;
+    const float len = std::sqrt(t);
+    if (len != 0.f) { nx = nx / len; ny = ny / len; nz = nz / len; } else { nx = 0.f; ny = 0.f; nz = 0.f; }
+    float d = nx * p0[0] + ny * p0[1]; d = d + nz * p0[2];
+    plane[0] = nx; plane[1] = ny; plane[2] = nz; plane[3] = -d;
+    return SURTR_OK;
+}
+
+// Kdop::KdopContainer::Calc(const Poly::Polyhedron&) (Src/Kdop.cpp:92-115): first minimum / first maximum of n.v over the
+// vertices in order; MinPlane = Plane(vert, -n), MaxPlane = Plane(vert, n) (point-normal form, not normalised:
+// SimpleMath.inl:2782-2788).  What k_refit computes on the device for every fragment, here for the Kdop API surface.
+int surtr_kdop_planes(uint32_t n, const float* points, uint32_t k, const float* normals, float* planes /* 8 floats per normal */)
+{
+    if (!points || !normals || !planes || n == 0) return SURTR_E_INVALID;
+    auto dot = [](const float* a, const float* b) { float t = a[0] * b[0] + a[1] * b[1]; return t + a[2] * b[2]; };
+    for (uint32_t j = 0; j < k; ++j)
+    {
+        const float* nr = normals + 3 * j;
+        double lo = 1.7976931348623157e308, hi = -1.7976931348623157e308;
+        uint32_t vlo = 0, vhi = 0;
+        for (uint32_t v = 0; v < n; ++v)
+        {
+            const float t = dot(points + 3 * v, nr);
+            if (lo > t) { lo = t; vlo = v; }
+            if (hi < t) { hi = t; vhi = v; }
+        }
+        for (int side = 0; side < 2; ++side)
+        {
+            const float nn[3] = {side ? nr[0] : -nr[0], side ? nr[1] : -nr[1], side ? nr[2] : -nr[2]};
+            const float* pv = points + 3 * (size_t)(side ? vhi : vlo);
+            float* out = planes + 8 * (size_t)j + 4 * side;
+            out[0] = nn[0]; out[1] = nn[1]; out[2] = nn[2]; out[3] = -dot(pv, nn);
+        }
+    }
+    return SURTR_OK;
+}
+
 // ---- mesh files either side of the path ----------------------------------------------
 // Surtr::LoadModelData (Src/Surtr.cpp:2683-2727) reads through assimp with Triangulate | FlipWindingOrder |
 // JoinIdenticalVertices, negates x and applies scale/translate.  assimp is not in this image; this reader restates

@@ -26,140 +26,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/surtr_hip.h"
-#include "clip_core.h"
-
-using namespace surtr;
-
-// ------------------------------------------------------------------ records
-struct PairRec
-{
-    uint32_t cv_off, cv_n, ch_off, ch_n;   // clipped Convex in the arena
-    uint32_t mv_off, mv_n, mh_off, mh_n;   // clipped Mesh (all islands, island-major)
-    uint32_t ni, isl_off;                  // islands and where their (nv, nh) records start
-    uint32_t status;
-    // reduced Mesh left in HBM by k_prep_pairs: img_fmt = IMG_*, offset in 16-byte units, vertices, ring entries,
-    // position slots reserved (>= the capacity of the topology that will clip it: positions are then used in place)
-    uint32_t img_fmt, img_off, img_n, img_h, img_pc;
-    // 1: the clip of the Convex ended in an inconsistent solid (degenerate input, where the reference produces an invalid
-    // polyhedron and carries on).  The pair goes on like the reference's: if nothing is left of the Mesh it yields no fragment
-    // and the event is fine; a fragment that would carry the invalid Convex fails the event with SURTR_E_TOPOLOGY.
-    uint32_t cv_bad;
-};
-
-enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
-       IMG_NARROW = 1,    // 16-bit image, loads straight into the LDS topology
-       IMG_WIDE = 2,      // the reduced solid does not fit the LDS topology: k_clip_pairs goes to global scratch directly
-       IMG_EMPTY = 3 };   // nothing of the Mesh is left
-
-// Byte offsets of the sections of one image (all 16-byte aligned): hist/zhist/nzero (F words each), the keep mask
-// (one word per 64 input vertices), then the reduced solid in the LDS layout, then its positions.
-struct ImgLayout { uint32_t hist, zhist, nzero, mask, loff, llen, comp, ring, pos, total; };
-__host__ __device__ static inline ImgLayout img_layout(uint32_t F, uint32_t nbV, uint32_t n, uint32_t hsum, uint32_t posCap = 0)
-{
-    auto up = [](uint32_t b) { return (b + 15u) & ~15u; };
-    ImgLayout L;
-    L.hist = 0; L.zhist = up(4u * F); L.nzero = L.zhist + up(4u * F); L.mask = L.nzero + up(4u * F); L.loff = L.mask + up(8u * nbV);
-    L.llen = L.loff + up(2u * n); L.comp = L.llen + up(n); L.ring = L.comp + up(n); L.pos = L.ring + up(2u * hsum);
-    L.total = L.pos + up(12u * (n > posCap ? n : posCap));      // positions last: room for the cut points of the clip
-    return L;
-}
-
-struct ImgArena { char* base; uint32_t cap16; };      // capacity in 16-byte units; cursor = Arena::cursors[10]
-
-// Per-workgroup scratch of k_prep_pairs: work lists of the pre-pass and (for very large solids) its masks.
-struct PrepPool { char* base; size_t per_wg; uint32_t VMAX; };
-static size_t prep_bytes_per_wg(uint32_t VMAX)
-{
-    auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
-}
-
-struct FragRec
-{
-    int32_t cell, piece, island;
-    uint32_t mv_off, mv_n, mh_off, mh_n;
-    uint32_t cv_off, cv_n, ch_off, ch_n;
-    uint32_t idx_off, idx_n;
-    // output bases (filled by k_out_scan)
-    uint32_t o_mv, o_mh, o_cv, o_ch, o_idx;
-};
-
-struct Arena
-{
-    float* pos; uint32_t* loff; uint32_t* llen; int32_t* nbr; uint32_t* idx;
-    uint2* isl;
-    uint32_t capV, capH, capI, capIsl;
-    uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=clip queue [5]=status [6]=refit queue [7]=faces queue [8]=convex queue
-                         // [9]=pre-pass queue [10]=image arena (16-byte units) [11]=big clip queue
-                         // [12]=half clip queue [13]=retry queue
-                         // [16..31]=pairs per cost class (k_prep_pairs) [32..47]=fragments per size class [48..63]=pairs per
-                         // pre-pass class [64..79]=pairs per cost class of k_clip_pairs_half (64 = its retry list)
-};
-
-struct Pieces
-{
-    const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri; const float* mrad;
-    const uint32_t* mperm; const float* mpos_s; const float* mrad_s; const float4* mbsph; const uint32_t* mbo;
-    const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri; const float* crad;
-    const uint32_t* cperm; const float* cpos_s; const float* crad_s; const float4* cbsph; const uint32_t* cbo;
-    uint32_t n;
-};
-
-struct ScratchPool
-{
-    char* base; size_t per_wg;
-    uint32_t CV, CH, VMAX;
-};
-
-// Per-workgroup global scratch: positions of the reduced solid (both variants), the wide (32-bit)
-// topology used when a solid does not fit the LDS one, three u32 work arrays, scan blocks, pre-pass masks.
-struct Scratch
-{
-    float* pos;
-    uint32_t* g_loff; uint32_t* g_llen; int8_t* g_comp; uint32_t* g_ring;
-    uint32_t* g_succ; uint32_t* g_pred; uint32_t* g_pcnt;
-    uint32_t* aux0; uint32_t* aux1; uint32_t* aux2; uint32_t* aux3;
-    int8_t* g_gcomp;       // explicit classification of a plane some live vertex lies in (both variants)
-    uint2* blk;
-    unsigned long long* gmask; uint2* gblk;
-    float* t_pos; uint32_t* t_loff; uint32_t* t_llen; int8_t* t_comp; uint32_t* t_ring;   // squeeze() staging
-    uint32_t CV, CH;
-};
-
-__device__ static Scratch carve(const ScratchPool& P, uint32_t wg)
-{
-    Scratch S;
-    char* p = P.base + (size_t)wg * P.per_wg;
-    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
-    S.pos = (float*)take((size_t)P.CV * 12);
-    S.g_loff = (uint32_t*)take((size_t)P.CV * 4);
-    S.g_llen = (uint32_t*)take((size_t)P.CV * 4);
-    S.g_comp = (int8_t*)take((size_t)P.CV);
-    S.g_ring = (uint32_t*)take((size_t)P.CH * 4);
-    S.g_succ = (uint32_t*)take((size_t)P.CV * 4);
-    S.g_pred = (uint32_t*)take((size_t)P.CV * 4);
-    S.g_pcnt = (uint32_t*)take((size_t)P.CV * 4);
-    S.aux0 = (uint32_t*)take((size_t)P.CV * 4);
-    S.aux1 = (uint32_t*)take((size_t)P.CV * 4);
-    S.aux2 = (uint32_t*)take((size_t)P.CV * 4);
-    S.aux3 = (uint32_t*)take((size_t)P.CV * 4);
-    S.g_gcomp = (int8_t*)take((size_t)P.CV);
-    S.blk = (uint2*)take((size_t)(P.CV / SURTR_LANES + 4) * 8);
-    S.gmask = (unsigned long long*)take((size_t)(P.VMAX / SURTR_LANES + 2) * 8);
-    S.gblk = (uint2*)take((size_t)(P.VMAX / SURTR_LANES + 2) * 8);
-    S.t_pos = (float*)take((size_t)P.CV * 12); S.t_loff = (uint32_t*)take((size_t)P.CV * 4); S.t_llen = (uint32_t*)take((size_t)P.CV * 4);
-    S.t_comp = (int8_t*)take((size_t)P.CV); S.t_ring = (uint32_t*)take((size_t)P.CH * 4);
-    S.CV = P.CV; S.CH = P.CH;
-    return S;
-}
-
-static size_t scratch_bytes_per_wg(uint32_t CV, uint32_t CH, uint32_t VMAX)
-{
-    auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 2 * r((size_t)CV * 12) + 11 * r((size_t)CV * 4) + 3 * r((size_t)CV) + 2 * r((size_t)CH * 4) + r((size_t)(CV / SURTR_LANES + 4) * 8) +
-           2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
-}
+#include "surtr_ctx.h"
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
 template <uint32_t LV, uint32_t LH>
@@ -177,16 +44,8 @@ typedef LdsTopoT<SURTR_LV, SURTR_LH> LdsTopo;          // Mesh solids: two workg
 typedef LdsTopoT<2 * SURTR_LV, 2 * SURTR_LH> LdsTopoBig;   // the few Mesh solids with a large band: one workgroup per CU
 // Half-size topology for the light pairs: four workgroups of 128 threads per CU (LdsTopoHalf + Shared <= 40 KiB).  These
 // kernels are bound by dependent round trips, not by lanes: half the lanes cost a pair ~1.3x, twice the pairs in flight win.
-#define SURTR_LVS (SURTR_LV / 2u)
-#define SURTR_LHS ((SURTR_LH * 11u / 24u) & ~7u)
 #define SURTR_WGS (SURTR_WG / 2u > SURTR_LANES ? SURTR_WG / 2u : SURTR_LANES)
 typedef LdsTopoT<SURTR_LVS, SURTR_LHS> LdsTopoHalf;
-// The half-size topology takes solids of up to half its capacity: thin bands can double under the cuts (measured on
-// BASELINE configs[3]: a fifth of the pairs admitted with 20 % room outgrew it), and a retry costs the pair twice.
-#ifndef SURTR_HALF_ROOM
-#define SURTR_HALF_ROOM 2u       // (tests build with 1 to make pairs outgrow it)
-#endif
-__host__ __device__ static inline bool fits_half(uint32_t n, uint32_t h, uint32_t capVs) { return SURTR_HALF_ROOM * n <= capVs && SURTR_HALF_ROOM * h <= SURTR_LHS; }
 // does a solid of n vertices / h ring entries leave a topology of capV / capH room to grow by the cuts?
 __host__ __device__ static inline bool fits_with_room(uint32_t n, uint32_t h, uint32_t capV, uint32_t capH)
 {
@@ -1318,10 +1177,6 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
 }
 
 // ------------------------------------------------------------------ k_faces
-struct FaceScratch
-{
-    int32_t* base; size_t per_wg; uint32_t HF;   // HF = max half-edges of one fragment
-};
 
 __device__ __forceinline__ bool on_right(const float* a, const float* b, const float* c, float nx, float ny, float nz)
 {
@@ -1492,9 +1347,14 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
 }
 #endif
 
+// fan != 0: RenderPolyhedron's isConvex branch (triangle fan per face, Src/Poly.cpp:696-706) instead of EarClipping.
+// face_n / face_off / face_idx (nullptr in an event): the face loops of Poly::ExtractFaces for the single-solid operators
+// (surtr_extract_faces: one fragment loaded); face_n = {faces, loop entries}.
 __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
-                                                    Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags)
+                                                    Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags,
+                                                    uint32_t fan, uint32_t* __restrict__ face_n, uint32_t* __restrict__ face_off,
+                                                    int32_t* __restrict__ face_idx, uint32_t* __restrict__ frag_status)
 {
     __shared__ Shared sh;
     // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
@@ -1685,7 +1545,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 return make_uint2(1u, len);
             };
             scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
-            if (lensum > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); failed = true; break; }
+            if (lensum > HF) { failed = true; break; }
             if (!irregular && lensum != H) pinched = true;
             const uint32_t nb = pinched ? 0u : (H + SURTR_LANES - 1u) >> SURTR_LSH;
             for (uint32_t b = wave_id(); b < nb; b += group_waves())
@@ -1761,7 +1621,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             nfaces = sh.misc[0]; lensum = sh.misc[1];
             const bool bad = sh.misc[2] != 0;
             __syncthreads();
-            if (bad) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_TOPOLOGY); failed = true; break; }
+            if (bad) { failed = true; break; }
         }
         __syncthreads();
         if (!pinched) break;
@@ -1769,12 +1629,42 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         if (tid == 0) sh.flagBad = 0;
         __syncthreads();
         }   // attempts
-        if (failed) continue;
+        if (failed)
+        {
+            // The reference's ExtractFaces never ends on this fragment (a walk that does not come back to its start vertex,
+            // Src/Poly.cpp:100-118): it gets no triangles and a status of its own; the other fragments of the event stand.
+            if (tid == 0)
+            {
+                frags[f].idx_off = 0; frags[f].idx_n = 0;
+                if (frag_status != nullptr) frag_status[f] = SURTR_E_TOPOLOGY;
+                atomicAdd(&A.cursors[14], 1u);
+            }
+            continue;
+        }
+        if (face_n != nullptr)
+        {
+            for (uint32_t fi = tid; fi < nfaces; fi += group_size()) face_off[fi] = (uint32_t)faceLo[fi];
+            for (uint32_t e = tid; e < lensum; e += group_size()) face_idx[e] = loopbuf[e];
+            if (tid == 0) { face_off[nfaces] = lensum; face_n[0] = nfaces; face_n[1] = lensum; }
+        }
         STAMP(62);
         // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
         //    room for 3*len indices at 3*lo
+        if (fan)
+        {
+            // isConvex: (f[0], f[v], f[v+1]) for v = 1 .. size-2 (Src/Poly.cpp:698-705)
+            for (uint32_t fi = tid; fi < nfaces; fi += group_size())
+            {
+                const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
+                uint32_t* out = tri + 3u * (size_t)lo;
+                const int32_t* loop = loopbuf + lo;
+                uint32_t at = 0;
+                for (uint32_t v = 1; v + 1u < len; ++v) { out[at] = (uint32_t)loop[0]; out[at + 1] = (uint32_t)loop[v]; out[at + 2] = (uint32_t)loop[v + 1]; at += 3u; }
+                fcnt[fi] = at;
+            }
+        }
 #ifndef SURTR_EMUL
-        for (uint32_t fi = wave_id(); fi < nfaces; fi += group_waves())
+        for (uint32_t fi = wave_id(); fi < (fan ? 0u : nfaces); fi += group_waves())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
             if (len < 5u || len > 64u) continue;
@@ -1784,7 +1674,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         __syncthreads();
         STAMP(63);
 #endif
-        for (uint32_t fi = tid; fi < nfaces; fi += group_size())
+        for (uint32_t fi = tid; fi < (fan ? 0u : nfaces); fi += group_size())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
 #ifndef SURTR_EMUL
@@ -1875,7 +1765,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
     if (threadIdx.x == 0)
     {
         counts->mesh_verts = mv; counts->mesh_nbrs = mh; counts->conv_verts = cv; counts->conv_nbrs = chh;
-        counts->n_idx = t0; counts->status = A.cursors[5];
+        counts->n_idx = t0; counts->status = A.cursors[5]; counts->n_failed = A.cursors[14];
     }
 }
 
@@ -1884,10 +1774,10 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
 //   header  surtr_counts (32 B)
 //   frag_ids i32[3*nf] | mesh_vert_off u32[nf+1] | mesh_pos f32[3*mv] | mesh_nbr_off u32[mv+1] | mesh_nbr i32[mh]
 //   conv_vert_off u32[nf+1] | conv_pos f32[3*cv] | conv_nbr_off u32[cv+1] | conv_nbr i32[ch]
-//   vnc f32[9*mv] | idx_off u32[nf+1] | idx u32[ni]
+//   vnc f32[9*mv] | idx_off u32[nf+1] | idx u32[ni] | frag_status u32[nf]
 struct BlobLayout
 {
-    size_t ids, mvo, mpos, mno, mnbr, cvo, cpos, cno, cnbr, vnc, ioff, idx, total;
+    size_t ids, mvo, mpos, mno, mnbr, cvo, cpos, cno, cnbr, vnc, ioff, idx, fstat, total;
 };
 
 __host__ __device__ static BlobLayout blob_layout(const surtr_counts& c)
@@ -1907,16 +1797,33 @@ __host__ __device__ static BlobLayout blob_layout(const surtr_counts& c)
     L.vnc = put((size_t)c.mesh_verts * 36);
     L.ioff = put(((size_t)c.n_frag + 1) * 4);
     L.idx = put((size_t)c.n_idx * 4);
+    L.fstat = put((size_t)c.n_frag * 4);
     L.total = at;
     return L;
 }
 
-__global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
-                                                   Arena A, char* __restrict__ blob, size_t capacity, uint32_t with_vnc)
+__global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ frags, surtr_counts* __restrict__ counts,
+                                                   Arena A, char* __restrict__ blob, size_t capacity, uint32_t with_vnc,
+                                                   const uint32_t* __restrict__ frag_status, float cr, float cg, float cb)
 {
     const surtr_counts c = *counts;
     const BlobLayout L = blob_layout(c);
-    if (L.total > capacity) return;
+    if (L.total > capacity)
+    {
+        // the caller's buffer is too small: say so in the blob header (zero counts) and in the event's status word, so
+        // that neither a stale nor a zero-filled blob is taken for a result
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+        {
+            atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY);
+            atomicMax(&counts->status, (uint32_t)SURTR_E_CAPACITY);
+            if (capacity >= sizeof(surtr_counts))
+            {
+                surtr_counts z; memset(&z, 0, sizeof(z)); z.n_pairs = c.n_pairs; z.status = SURTR_E_CAPACITY;
+                *(surtr_counts*)blob = z;
+            }
+        }
+        return;
+    }
     const uint32_t nf = c.n_frag, tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0)
     {
@@ -1937,6 +1844,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ f
             ((uint32_t*)(blob + L.mvo))[f] = fr.o_mv;
             ((uint32_t*)(blob + L.cvo))[f] = fr.o_cv;
             ((uint32_t*)(blob + L.ioff))[f] = fr.o_idx;
+            ((uint32_t*)(blob + L.fstat))[f] = frag_status[f];
         }
         float* mpos = (float*)(blob + L.mpos) + 3 * (size_t)fr.o_mv;
         const float* sp = A.pos + 3 * (size_t)fr.mv_off;
@@ -1954,12 +1862,12 @@ __global__ __launch_bounds__(SURTR_WG) void k_pack(const FragRec* __restrict__ f
         for (uint32_t e = tid; e < fr.ch_n; e += group_size()) cnbr[e] = A.nbr[fr.ch_off + e];
         if (with_vnc)
         {
-            // VertexNormalColor{pos, (0,0,0), (0.25,0.25,0.25)} (Src/Poly.cpp:690-694)
+            // VertexNormalColor{pos, (0,0,0), color} (Src/Poly.cpp:690-694; the default colour is 0.25 grey, Inc/Poly.h:68)
             float* vnc = (float*)(blob + L.vnc) + 9 * (size_t)fr.o_mv;
             for (uint32_t i = tid; i < 9 * fr.mv_n; i += group_size())
             {
                 const uint32_t v = i / 9, k = i % 9;
-                vnc[i] = k < 3 ? sp[3 * v + k] : (k < 6 ? 0.f : 0.25f);
+                vnc[i] = k < 3 ? sp[3 * v + k] : (k < 6 ? 0.f : (k == 6 ? cr : (k == 7 ? cg : cb)));
             }
         }
         uint32_t* idx = (uint32_t*)(blob + L.idx) + fr.o_idx;
@@ -1992,89 +1900,6 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
 }
 
 // =================================================================== host ===
-struct surtr_ctx
-{
-    int device = 0;
-    uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;
-    ScratchPool pool_half{}; uint32_t n_wg_half = 0;       // k_clip_pairs_half: scratch for the half-size LDS topology only
-    // Light pairs go to k_clip_pairs_half only when they are most of the event (small pieces: refracture).  Beside a
-    // full k_clip_pairs a third kernel costs more than it gains (configs[3]: +0.2 ms even when its workgroups exit at
-    // once), and what a large piece leaves of itself in a cell is seldom small enough.  Decided per upload from the piece sizes.
-    bool half_on = false;
-    PrepPool prep{nullptr, 0, 0}; uint32_t n_wg_prep = 0;
-    ImgArena img{nullptr, 0};
-    uint32_t* d_order = nullptr; uint32_t cap_order = 0;
-    uint32_t* d_forder = nullptr;    // fragments by size class, 16 x cap_frags
-    uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
-#ifndef SURTR_EMUL
-    hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
-    hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both
-    hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr;
-#endif
-    hipStream_t stream = nullptr;
-    std::string err;
-    // pieces
-    uint32_t n_pieces = 0, vmax = 0, hmax = 0, cvmax = 0, chmax = 0;
-    float *d_mpos = nullptr, *d_cpos = nullptr;
-    uint32_t *d_mloff = nullptr, *d_mllen = nullptr, *d_mvo = nullptr, *d_cloff = nullptr, *d_cllen = nullptr, *d_cvo = nullptr;
-    int32_t *d_mnbr = nullptr, *d_cnbr = nullptr;
-    uint8_t *d_mtri = nullptr, *d_ctri = nullptr;
-    float *d_mrad = nullptr, *d_crad = nullptr;
-    uint32_t *d_mperm = nullptr, *d_cperm = nullptr, *d_mbo = nullptr, *d_cbo = nullptr;
-    float *d_mpos_s = nullptr, *d_cpos_s = nullptr, *d_mrad_s = nullptr, *d_crad_s = nullptr;
-    float4 *d_mbsph = nullptr, *d_cbsph = nullptr;
-    uint64_t tot_mv = 0, tot_mh = 0;
-    // cells
-    uint32_t n_cells = 0, n_faces = 0;
-    uint32_t* d_pair_order = nullptr; uint32_t pair_order_begin = 0, pair_order_count = 0, cap_pair_order = 0;   // k_clip_convex: pairs by plane count
-    bool pair_order_is_list = false;
-    float* d_v012 = nullptr; float4* d_planes = nullptr; uint32_t* d_plane_off = nullptr;
-    std::vector<uint32_t> h_plane_off;
-    bool planes_ready = false;
-    // scratch + arena
-    uint32_t user_cv = 0, user_ch = 0;
-    uint64_t user_av = 0, user_ah = 0, user_ai = 0;
-    ScratchPool pool{}; uint32_t n_wg = 0;
-    ScratchPool pool_small{}; uint32_t n_wg_small = 0;      // one-wave kernels (Convex clip, refit)
-    FaceScratch fs{}; uint2* d_blk = nullptr; uint32_t blk_per_wg = 0;
-    Arena arena{};
-    PairRec* d_pairs = nullptr; uint32_t cap_pairs = 0;
-    FragRec* d_frags = nullptr; uint32_t cap_frags = 0;
-    uint2* d_scanblk = nullptr; uint32_t cap_scanblk = 0;
-    surtr_counts* d_counts = nullptr;
-    uint8_t* d_outside = nullptr;
-    uint2* d_pair_list = nullptr; uint32_t cap_pair_list = 0;
-    surtr_counts last{};
-    bool have_event = false; uint32_t last_flags = 0;
-    // staging for downloads
-    void* d_blob = nullptr; size_t blob_cap = 0;
-    // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
-    bool profiling = false;
-#ifndef SURTR_EMUL
-    hipEvent_t ev[32] = {};     // begin/end per kernel slot 0..15
-#endif
-    bool ev_valid[16] = {};
-};
-
-#ifndef SURTR_EMUL
-#define PROF_BEGIN_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], strm); } } while (0)
-#define PROF_END_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], strm); ctx->ev_valid[i] = true; } } while (0)
-#define PROF_BEGIN(i) PROF_BEGIN_ON(i, st)
-#define PROF_END(i) PROF_END_ON(i, st)
-#else
-#define PROF_BEGIN(i) do { } while (0)
-#define PROF_END(i) do { } while (0)
-#define PROF_BEGIN_ON(i, strm) do { } while (0)
-#define PROF_END_ON(i, strm) do { } while (0)
-#endif
-
-#define HIPCHK(call)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (call);                                                                   \
-        if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return SURTR_E_HIP; } \
-    } while (0)
-
-static void free_dev(void* p) { if (p) (void)hipFree(p); }
 
 extern "C" {
 
@@ -2140,11 +1965,8 @@ void surtr_destroy(surtr_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    free_dev(ctx->d_mpos); free_dev(ctx->d_cpos); free_dev(ctx->d_mloff); free_dev(ctx->d_mllen); free_dev(ctx->d_mvo);
-    free_dev(ctx->d_cloff); free_dev(ctx->d_cllen); free_dev(ctx->d_cvo); free_dev(ctx->d_mnbr); free_dev(ctx->d_cnbr);
-    free_dev(ctx->d_mtri); free_dev(ctx->d_ctri); free_dev(ctx->d_mrad); free_dev(ctx->d_crad);
-    free_dev(ctx->d_mperm); free_dev(ctx->d_cperm); free_dev(ctx->d_mbo); free_dev(ctx->d_cbo); free_dev(ctx->d_mpos_s); free_dev(ctx->d_cpos_s);
-    free_dev(ctx->d_mrad_s); free_dev(ctx->d_crad_s); free_dev(ctx->d_mbsph); free_dev(ctx->d_cbsph);
+    ctx->mset.release(); ctx->cset.release();
+    free_dev(ctx->d_upload_err); free_dev(ctx->d_world); free_dev(ctx->sort_tmp); free_dev(ctx->d_from);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->d_pair_order);
@@ -2159,7 +1981,7 @@ void surtr_destroy(surtr_ctx* ctx)
 #endif
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
-    free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
+    free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_frag_status); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
     free_dev(ctx->d_outside); free_dev(ctx->d_blob); free_dev(ctx->d_pair_list);
     delete ctx;
 }
@@ -2206,203 +2028,6 @@ static int check_solid(uint32_t nv, const uint32_t* off, const int32_t* nbr)
             if (!back) return SURTR_E_TOPOLOGY;
         }
     }
-    return SURTR_OK;
-}
-
-static int upload_set(surtr_ctx* ctx, uint32_t n, const uint32_t* vo, const float* pos, const uint32_t* off, const int32_t* nbr,
-                      float** d_pos, uint32_t** d_loff, uint32_t** d_llen, int32_t** d_nbr, uint32_t** d_vo, uint8_t** d_tri, float** d_rad,
-                      uint32_t** d_perm, float** d_pos_s, float** d_rad_s, float4** d_bsph, uint32_t** d_bo,
-                      uint32_t& vmax, uint32_t& hmax, uint64_t& totv, uint64_t& toth)
-{
-    const uint32_t V = vo[n];
-    const uint32_t H = off[V];
-    std::vector<uint32_t> llen(V);
-    for (uint32_t p = 0; p < n; ++p)
-    {
-        const uint32_t a = vo[p], b = vo[p + 1];
-        if (b < a || b - a < 4 || b - a >= (1u << 24)) return SURTR_E_INVALID;     // the pre-pass packs (vertex, plane) in 32 bits
-        // local CSR view of this solid
-        std::vector<uint32_t> loc(b - a + 1);
-        for (uint32_t v = a; v <= b; ++v) loc[v - a] = off[v] - off[a];
-        int rc = check_solid(b - a, loc.data(), nbr + off[a]);
-        if (rc) return rc;
-        vmax = std::max(vmax, b - a);
-        hmax = std::max(hmax, off[b] - off[a]);
-    }
-    for (uint32_t v = 0; v < V; ++v) llen[v] = off[v + 1] - off[v];
-    // tri[v] = 1 when every face around v is a triangle (then the 1-ring holds all vertices of its faces)
-    std::vector<uint8_t> tri(V, 1);
-    for (uint32_t p = 0; p < n; ++p)
-    {
-        const uint32_t a = vo[p], b = vo[p + 1];
-        auto ring = [&](int32_t lv) { return nbr + off[a + lv]; };
-        auto rlen = [&](int32_t lv) { return off[a + lv + 1] - off[a + lv]; };
-        auto prevof = [&](int32_t lv, int32_t who) {
-            const int32_t* r = ring(lv); const uint32_t len = rlen(lv);
-            uint32_t k = 0;
-            while (k < len && r[k] != who) ++k;
-            return k == 0 ? r[len - 1] : r[k - 1];
-        };
-        for (uint32_t v = a; v < b; ++v)
-        {
-            const int32_t lv = (int32_t)(v - a);
-            for (uint32_t j = off[v]; j < off[v + 1]; ++j)
-            {
-                const int32_t x = nbr[j];
-                const int32_t y = prevof(x, lv);
-                if (y == lv || prevof(y, x) != lv) { tri[v] = 0; break; }
-            }
-        }
-    }
-    // rad[v] = radius of a ball around v that holds every vertex of every face incident to v
-    std::vector<float> rad(V, 0.f);
-    for (uint32_t p = 0; p < n; ++p)
-    {
-        const uint32_t a = vo[p], b = vo[p + 1];
-        auto ringp = [&](int32_t lv) { return nbr + off[a + lv]; };
-        auto rlenp = [&](int32_t lv) { return off[a + lv + 1] - off[a + lv]; };
-        auto prevof2 = [&](int32_t lv, int32_t who) {
-            const int32_t* r = ringp(lv); const uint32_t len = rlenp(lv);
-            uint32_t k = 0;
-            while (k < len && r[k] != who) ++k;
-            return k == 0 ? r[len - 1] : r[k - 1];
-        };
-        auto dist = [&](uint32_t x, uint32_t y) {
-            const double dx = (double)pos[3 * (size_t)x] - pos[3 * (size_t)y], dy = (double)pos[3 * (size_t)x + 1] - pos[3 * (size_t)y + 1],
-                         dz = (double)pos[3 * (size_t)x + 2] - pos[3 * (size_t)y + 2];
-            return std::sqrt(dx * dx + dy * dy + dz * dz);
-        };
-        for (uint32_t v = a; v < b; ++v)
-        {
-            double r = 0.0;
-            const int32_t lv = (int32_t)(v - a);
-            for (uint32_t j = off[v]; j < off[v + 1]; ++j)
-            {
-                r = std::max(r, dist(v, a + nbr[j]));
-                if (!tri[v])
-                {
-                    int32_t prev = lv, cur = nbr[j]; uint32_t steps = 0;
-                    while (cur != lv && steps++ < b - a)
-                    {
-                        r = std::max(r, dist(v, a + cur));
-                        const int32_t nx = prevof2(cur, prev);
-                        prev = cur; cur = nx;
-                    }
-                }
-            }
-            rad[v] = (float)(r * 1.000001) + 1e-30f;
-        }
-    }
-    free_dev(*d_pos); free_dev(*d_tri); *d_tri = nullptr; free_dev(*d_rad); *d_rad = nullptr; free_dev(*d_loff); free_dev(*d_llen); free_dev(*d_nbr); free_dev(*d_vo);
-    *d_pos = nullptr; *d_loff = nullptr; *d_llen = nullptr; *d_nbr = nullptr; *d_vo = nullptr;
-    HIPCHK(hipMalloc((void**)d_pos, std::max<size_t>(16, (size_t)V * 12)));
-    HIPCHK(hipMalloc((void**)d_loff, std::max<size_t>(16, (size_t)(V + 1) * 4)));
-    HIPCHK(hipMalloc((void**)d_llen, std::max<size_t>(16, (size_t)V * 4)));
-    HIPCHK(hipMalloc((void**)d_nbr, std::max<size_t>(16, (size_t)H * 4)));
-    HIPCHK(hipMalloc((void**)d_vo, (size_t)(n + 1) * 4));
-    HIPCHK(hipMemcpy(*d_pos, pos, (size_t)V * 12, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d_loff, off, (size_t)(V + 1) * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d_llen, llen.data(), (size_t)V * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*d_vo, vo, (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)d_tri, std::max<size_t>(16, (size_t)V)));
-    HIPCHK(hipMemcpy(*d_tri, tri.data(), (size_t)V, hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)d_rad, std::max<size_t>(16, (size_t)V * 4)));
-    HIPCHK(hipMemcpy(*d_rad, rad.data(), (size_t)V * 4, hipMemcpyHostToDevice));
-    // Spatially sorted copy for the pre-pass: Morton order per piece, 64-vertex blocks with a bounding sphere that
-    // also holds every vertex's ball (radius rad[v]).
-    {
-        std::vector<uint32_t> perm(V), bo(n + 1, 0);
-        std::vector<float> pos_s(3 * (size_t)V), rad_s(V);
-        std::vector<float> bs;
-        for (uint32_t p = 0; p < n; ++p)
-        {
-            const uint32_t a = vo[p], b = vo[p + 1], m = b - a;
-            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-            for (uint32_t v = a; v < b; ++v) for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], (double)pos[3 * (size_t)v + c]); hi[c] = std::max(hi[c], (double)pos[3 * (size_t)v + c]); }
-            std::vector<std::pair<uint32_t, uint32_t>> key(m);
-            for (uint32_t v = 0; v < m; ++v)
-            {
-                uint32_t code = 0;
-                for (int c = 0; c < 3; ++c)
-                {
-                    const double ext = hi[c] - lo[c];
-                    uint32_t q = ext > 0 ? (uint32_t)std::min(1023.0, std::max(0.0, (pos[3 * (size_t)(a + v) + c] - lo[c]) / ext * 1024.0)) : 0u;
-                    for (int bit = 0; bit < 10; ++bit) code |= ((q >> bit) & 1u) << (3 * bit + c);
-                }
-                key[v] = {code, v};
-            }
-            std::sort(key.begin(), key.end());
-            for (uint32_t i = 0; i < m; ++i)
-            {
-                const uint32_t v = key[i].second;
-                perm[a + i] = v;
-                for (int c = 0; c < 3; ++c) pos_s[3 * (size_t)(a + i) + c] = pos[3 * (size_t)(a + v) + c];
-                rad_s[a + i] = rad[a + v];
-            }
-            const uint32_t nb = (m + SURTR_SB - 1) / SURTR_SB;
-            for (uint32_t blk = 0; blk < nb; ++blk)
-            {
-                const uint32_t i0 = blk * SURTR_SB, i1 = std::min(m, i0 + (uint32_t)SURTR_SB);
-                double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
-                for (uint32_t i = i0; i < i1; ++i) for (int c = 0; c < 3; ++c) { blo[c] = std::min(blo[c], (double)pos_s[3 * (size_t)(a + i) + c]); bhi[c] = std::max(bhi[c], (double)pos_s[3 * (size_t)(a + i) + c]); }
-                const float cx = (float)((blo[0] + bhi[0]) / 2), cy = (float)((blo[1] + bhi[1]) / 2), cz = (float)((blo[2] + bhi[2]) / 2);
-                double R = 0;
-                for (uint32_t i = i0; i < i1; ++i)
-                {
-                    const double dx = pos_s[3 * (size_t)(a + i)] - (double)cx, dy = pos_s[3 * (size_t)(a + i) + 1] - (double)cy, dz = pos_s[3 * (size_t)(a + i) + 2] - (double)cz;
-                    R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + (double)rad_s[a + i]);
-                }
-                bs.push_back(cx); bs.push_back(cy); bs.push_back(cz); bs.push_back((float)(R * 1.000001) + 1e-30f);
-            }
-            bo[p + 1] = bo[p] + nb;
-        }
-        free_dev(*d_perm); free_dev(*d_pos_s); free_dev(*d_rad_s); free_dev(*d_bsph); free_dev(*d_bo);
-        *d_perm = nullptr; *d_pos_s = nullptr; *d_rad_s = nullptr; *d_bsph = nullptr; *d_bo = nullptr;
-        HIPCHK(hipMalloc((void**)d_perm, std::max<size_t>(16, (size_t)V * 4)));
-        HIPCHK(hipMalloc((void**)d_pos_s, std::max<size_t>(16, (size_t)V * 12)));
-        HIPCHK(hipMalloc((void**)d_rad_s, std::max<size_t>(16, (size_t)V * 4)));
-        HIPCHK(hipMalloc((void**)d_bsph, std::max<size_t>(16, bs.size() * 4)));
-        HIPCHK(hipMalloc((void**)d_bo, (size_t)(n + 1) * 4));
-        HIPCHK(hipMemcpy(*d_perm, perm.data(), (size_t)V * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(*d_pos_s, pos_s.data(), (size_t)V * 12, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(*d_rad_s, rad_s.data(), (size_t)V * 4, hipMemcpyHostToDevice));
-        if (!bs.empty()) HIPCHK(hipMemcpy(*d_bsph, bs.data(), bs.size() * 4, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(*d_bo, bo.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
-    }
-    totv = V; toth = H;
-    return SURTR_OK;
-}
-
-int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const float* mpos, const uint32_t* moff,
-                        const int32_t* mnbr, const uint32_t* cvo, const float* cpos, const uint32_t* coff, const int32_t* cnbr)
-{
-    if (!ctx || n == 0 || !mvo || !mpos || !moff || !mnbr || !cvo || !cpos || !coff || !cnbr) return SURTR_E_INVALID;
-    (void)hipSetDevice(ctx->device);
-    uint32_t vmax = 0, hmax = 0; uint64_t tv = 0, th = 0, cv = 0, chh = 0;
-    int rc = upload_set(ctx, n, mvo, mpos, moff, mnbr, &ctx->d_mpos, &ctx->d_mloff, &ctx->d_mllen, &ctx->d_mnbr, &ctx->d_mvo, &ctx->d_mtri, &ctx->d_mrad,
-                        &ctx->d_mperm, &ctx->d_mpos_s, &ctx->d_mrad_s, &ctx->d_mbsph, &ctx->d_mbo,
-                        vmax, hmax, tv, th);
-    if (rc) return rc;
-    uint32_t cvmax = 0, chmax = 0;
-    rc = upload_set(ctx, n, cvo, cpos, coff, cnbr, &ctx->d_cpos, &ctx->d_cloff, &ctx->d_cllen, &ctx->d_cnbr, &ctx->d_cvo, &ctx->d_ctri, &ctx->d_crad,
-                    &ctx->d_cperm, &ctx->d_cpos_s, &ctx->d_crad_s, &ctx->d_cbsph, &ctx->d_cbo,
-                    cvmax, chmax, cv, chh);
-    if (rc) return rc;
-    ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
-    ctx->tot_mv = tv; ctx->tot_mh = th; ctx->pair_order_count = 0;
-    {
-        uint32_t small = 0;
-        for (uint32_t i = 0; i < n; ++i)
-            if (fits_half((mvo[i + 1] - mvo[i]) / 4u, (moff[mvo[i + 1]] - moff[mvo[i]]) / 4u, SURTR_LVS)) ++small;      // what a cell keeps of it is likely light
-        ctx->half_on = 4ull * small >= 3ull * n;
-        if (const char* e = getenv("SURTR_HALF")) ctx->half_on = atoi(e) != 0;      // tests: force either way
-    }
-    free_dev(ctx->pool_small.base); ctx->pool_small.base = nullptr;
-    free_dev(ctx->pool.base); ctx->pool.base = nullptr;      // re-size scratch lazily
-    free_dev(ctx->d_outside); ctx->d_outside = nullptr;
-    HIPCHK(hipMalloc((void**)&ctx->d_outside, std::max<uint32_t>(n, 16)));
-    ctx->have_event = false;
     return SURTR_OK;
 }
 
@@ -2540,7 +2165,7 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
     return SURTR_OK;
 }
 
-static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
+static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs, uint64_t min_v = 0, uint64_t min_h = 0, uint64_t min_i = 0)
 {
     // Result sizes are data dependent.  Cells partition space, so the Mesh fragments of an event add up to the pieces plus
     // their cut points: the default reserves three times all pieces (at least eight times the largest one) plus slack per pair
@@ -2548,23 +2173,37 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs)
     uint64_t av = ctx->user_av ? ctx->user_av : std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctx->vmax * 8, ctx->tot_mv * 3) + (uint64_t)n_pairs * 256, 1u << 16);
     uint64_t ah = ctx->user_ah ? ctx->user_ah : std::max<uint64_t>(std::max<uint64_t>((uint64_t)ctx->hmax * 8, ctx->tot_mh * 3) + (uint64_t)n_pairs * 1024, 1u << 18);
     uint64_t ai = ctx->user_ai ? ctx->user_ai : ah * 2;
+    av = std::max(av, min_v); ah = std::max(ah, min_h); ai = std::max(ai, min_i);
     av = std::min<uint64_t>(av, 0xFFFFFFF0ull); ah = std::min<uint64_t>(ah, 0xFFFFFFF0ull); ai = std::min<uint64_t>(ai, 0xFFFFFFF0ull);
     const uint32_t capIsl = (uint32_t)std::min<uint64_t>((uint64_t)n_pairs * 4 + 1024, 0x7FFFFFFFull);
     if (!(ctx->arena.pos && ctx->arena.capV >= av && ctx->arena.capH >= ah && ctx->arena.capI >= ai && ctx->arena.capIsl >= capIsl))
     {
         free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
-        free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->d_frags);
+        free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->d_frags); free_dev(ctx->d_frag_status);
         ctx->arena.pos = nullptr; ctx->arena.loff = nullptr; ctx->arena.llen = nullptr; ctx->arena.nbr = nullptr;
-        ctx->arena.idx = nullptr; ctx->arena.isl = nullptr; ctx->d_frags = nullptr;
-        HIPCHK(hipMalloc((void**)&ctx->arena.pos, av * 12));
-        HIPCHK(hipMalloc((void**)&ctx->arena.loff, av * 4));
-        HIPCHK(hipMalloc((void**)&ctx->arena.llen, av * 4));
-        HIPCHK(hipMalloc((void**)&ctx->arena.nbr, ah * 4));
-        HIPCHK(hipMalloc((void**)&ctx->arena.idx, ai * 4));
-        HIPCHK(hipMalloc((void**)&ctx->arena.isl, (size_t)capIsl * 8));
-        HIPCHK(hipMalloc((void**)&ctx->d_frags, (size_t)capIsl * sizeof(FragRec)));
+        ctx->arena.idx = nullptr; ctx->arena.isl = nullptr; ctx->d_frags = nullptr; ctx->d_frag_status = nullptr;
+        ctx->arena.capV = ctx->arena.capH = ctx->arena.capI = ctx->arena.capIsl = 0; ctx->cap_frags = 0;
         free_dev(ctx->d_forder); ctx->d_forder = nullptr;
-        HIPCHK(hipMalloc((void**)&ctx->d_forder, (size_t)capIsl * 16 * 4));
+        hipError_t e = hipMalloc((void**)&ctx->arena.pos, av * 12);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->arena.loff, av * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->arena.llen, av * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->arena.nbr, ah * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->arena.idx, ai * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->arena.isl, (size_t)capIsl * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_frags, (size_t)capIsl * sizeof(FragRec));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_forder, (size_t)capIsl * 16 * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_frag_status, (size_t)capIsl * 4);
+        if (e != hipSuccess)
+        {
+            // out of memory half-way: leave no buffer behind, so that a later, smaller event allocates afresh
+            free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
+            free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->d_frags); free_dev(ctx->d_forder); free_dev(ctx->d_frag_status);
+            ctx->d_frag_status = nullptr;
+            ctx->arena.pos = nullptr; ctx->arena.loff = nullptr; ctx->arena.llen = nullptr; ctx->arena.nbr = nullptr;
+            ctx->arena.idx = nullptr; ctx->arena.isl = nullptr; ctx->d_frags = nullptr; ctx->d_forder = nullptr;
+            ctx->err = std::string("arena allocation: ") + hipGetErrorString(e);
+            return SURTR_E_HIP;
+        }
         ctx->arena.capV = (uint32_t)av; ctx->arena.capH = (uint32_t)ah; ctx->arena.capI = (uint32_t)ai; ctx->arena.capIsl = capIsl;
         ctx->cap_frags = capIsl;
     }
@@ -2592,7 +2231,10 @@ static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pai
         HIPCHK(hipMalloc((void**)&ctx->d_pair_order, (size_t)n_pairs * 4));
         ctx->cap_pair_order = n_pairs;
     }
-    HIPCHK(hipMemcpy(ctx->d_pair_order, ord, (size_t)n_pairs * 4, hipMemcpyHostToDevice));
+    // a previous event (possibly still running on a non-blocking stream) may be reading the table
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_pair_order, ord, (size_t)n_pairs * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));     // `ord` is the caller's staging buffer
     return SURTR_OK;
 }
 
@@ -2618,14 +2260,16 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 512, st));
     HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
+    HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
     const uint8_t* d_out = nullptr;
     if (outside)
     {
         HIPCHK(hipMemcpyAsync(ctx->d_outside, outside, ctx->n_pieces, hipMemcpyHostToDevice, st));
         d_out = ctx->d_outside;
     }
-    Pieces P{ctx->d_mpos, ctx->d_mloff, ctx->d_mllen, ctx->d_mnbr, ctx->d_mvo, ctx->d_mtri, ctx->d_mrad, ctx->d_mperm, ctx->d_mpos_s, ctx->d_mrad_s, ctx->d_mbsph, ctx->d_mbo,
-             ctx->d_cpos, ctx->d_cloff, ctx->d_cllen, ctx->d_cnbr, ctx->d_cvo, ctx->d_ctri, ctx->d_crad, ctx->d_cperm, ctx->d_cpos_s, ctx->d_crad_s, ctx->d_cbsph, ctx->d_cbo, ctx->n_pieces};
+    const PieceSet& M = ctx->mset; const PieceSet& C = ctx->cset;
+    Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.pos_s, M.rad_s, M.bsph, M.bo,
+             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.pos_s, C.rad_s, C.bsph, C.bo, ctx->n_pieces};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     const uint32_t* d_pair_order = nullptr;
     if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it
@@ -2722,7 +2366,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     {
         PROF_BEGIN(3);
         hipLaunchKernelGGL(k_faces, dim3(std::max(n_wg, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
-                           ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags);
+                           ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
+                           ctx->d_frag_status);
         PROF_END(3);
     }
 #ifndef SURTR_EMUL
@@ -2736,7 +2381,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     PROF_END(4);
     HIPCHK(hipGetLastError());
-    ctx->have_event = true; ctx->last_flags = flags;
+    ctx->have_event = true; ctx->last_flags = flags; ctx->last_current = false;
     return SURTR_OK;
 }
 
@@ -2828,8 +2473,186 @@ int surtr_event_refit(surtr_ctx* ctx)
     PROF_END(2);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
-    ctx->last_flags |= SURTR_EVT_REFIT;
+    ctx->last_flags |= SURTR_EVT_REFIT; ctx->last_current = false;
     return SURTR_OK;
+}
+
+// k_faces on the current fragments (an event's, or those of surtr_load_fragments).
+static int launch_faces(surtr_ctx* ctx, uint32_t fan, uint32_t* d_face_n, uint32_t* d_face_off, int32_t* d_face_idx)
+{
+    hipStream_t st = ctx->stream;
+    // queue 7 = fragments for k_faces, cursor 2 = index arena, 14 = fragments without triangles
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors + 7, 0, 4, st));
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors + 2, 0, 4, st));
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors + 14, 0, 4, st));
+    HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
+    PROF_BEGIN(3);
+    hipLaunchKernelGGL(k_faces, dim3(std::max(1u, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
+                       ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, fan, d_face_n, d_face_off, d_face_idx, ctx->d_frag_status);
+    PROF_END(3);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    HIPCHK(hipGetLastError());
+    ctx->last_flags |= SURTR_EVT_RENDER; ctx->last_current = false;
+    return SURTR_OK;
+}
+
+int surtr_event_triangulate(surtr_ctx* ctx, int is_convex)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    if (!ctx->have_event) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    return launch_faces(ctx, is_convex ? 1u : 0u, nullptr, nullptr, nullptr);
+}
+
+int surtr_load_fragments(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const float* mpos, const uint32_t* moff, const int32_t* mnbr,
+                         const uint32_t* cvo, const float* cpos, const uint32_t* coff, const int32_t* cnbr, const int32_t* frag_ids)
+{
+    if (!ctx || n == 0 || !mvo || !mpos || !moff || !mnbr || !cvo || !cpos || !coff || !cnbr) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    const uint32_t MV = mvo[n], CV = cvo[n];
+    const uint32_t MH = moff[MV], CH = coff[CV];
+    uint32_t vmax = 0, hmax = 0, cvmax = 0, chmax = 0;
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        for (int set = 0; set < 2; ++set)
+        {
+            const uint32_t* vo = set ? cvo : mvo; const uint32_t* off = set ? coff : moff; const int32_t* nbr = set ? cnbr : mnbr;
+            const uint32_t a = vo[k], b = vo[k + 1];
+            if (b < a || b - a < 4) return SURTR_E_INVALID;
+            std::vector<uint32_t> loc(b - a + 1);
+            for (uint32_t v = a; v <= b; ++v) loc[v - a] = off[v] - off[a];
+            const int rc = check_solid(b - a, loc.data(), nbr + off[a]);
+            if (rc) return rc;
+            if (set) { cvmax = std::max(cvmax, b - a); chmax = std::max(chmax, off[b] - off[a]); }
+            else { vmax = std::max(vmax, b - a); hmax = std::max(hmax, off[b] - off[a]); }
+        }
+    }
+    ctx->cvmax = std::max(ctx->cvmax, cvmax); ctx->chmax = std::max(ctx->chmax, chmax);
+    ctx->vmax = std::max(ctx->vmax, std::max(vmax, cvmax)); ctx->hmax = std::max(ctx->hmax, std::max(hmax, chmax));
+    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(1u, ctx->n_wg));
+    if (rc) return rc;
+    rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
+    if (rc) return rc;
+    // the solids, the refitted Convex solids (a clip by 8 planes adds a few vertices per plane), 3 indices per half-edge at most
+    rc = ensure_arena(ctx, n, (uint64_t)MV + 3ull * CV + 64ull * n, (uint64_t)MH + 4ull * CH + 256ull * n, 3ull * MH + 64);
+    if (rc) return rc;
+    if (n > ctx->cap_frags) return SURTR_E_CAPACITY;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint32_t> loff((size_t)MV + CV), llen((size_t)MV + CV);
+    for (uint32_t v = 0; v < MV; ++v) { loff[v] = moff[v]; llen[v] = moff[v + 1] - moff[v]; }
+    for (uint32_t v = 0; v < CV; ++v) { loff[MV + v] = MH + coff[v]; llen[MV + v] = coff[v + 1] - coff[v]; }
+    std::vector<FragRec> fr(n);
+    std::vector<uint32_t> cursors(128, 0u), forder((size_t)16 * ctx->cap_frags, 0u);
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        FragRec& r = fr[k];
+        memset(&r, 0, sizeof(r));
+        r.cell = frag_ids ? frag_ids[3 * k] : (int32_t)k; r.piece = frag_ids ? frag_ids[3 * k + 1] : 0; r.island = frag_ids ? frag_ids[3 * k + 2] : 0;
+        r.mv_off = mvo[k]; r.mv_n = mvo[k + 1] - mvo[k]; r.mh_off = moff[mvo[k]]; r.mh_n = moff[mvo[k + 1]] - moff[mvo[k]];
+        r.cv_off = MV + cvo[k]; r.cv_n = cvo[k + 1] - cvo[k]; r.ch_off = MH + coff[cvo[k]]; r.ch_n = coff[cvo[k + 1]] - coff[cvo[k]];
+        uint32_t cls = 0; while ((r.mv_n >> (cls + 1u)) != 0u && cls < 15u) ++cls;      // size classes of k_frag_table
+        forder[(size_t)cls * ctx->cap_frags + cursors[32u + cls]++] = k;
+    }
+    cursors[0] = MV + CV; cursors[1] = MH + CH;
+    surtr_counts c; memset(&c, 0, sizeof(c)); c.n_frag = n; c.n_pairs = n;
+    HIPCHK(hipMemcpyAsync(ctx->arena.pos, mpos, (size_t)MV * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.pos + 3 * (size_t)MV, cpos, (size_t)CV * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.loff, loff.data(), loff.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.llen, llen.data(), llen.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.nbr, mnbr, (size_t)MH * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.nbr + MH, cnbr, (size_t)CH * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_frags, fr.data(), (size_t)n * sizeof(FragRec), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_forder, forder.data(), forder.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->arena.cursors, cursors.data(), 512, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_counts, &c, sizeof(c), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));       // the staging vectors go out of scope
+    ctx->have_event = true; ctx->last_flags = 0; ctx->last_current = false;
+    return SURTR_OK;
+}
+
+// One solid as the only fragment (its own Mesh; `conv` or the solid again as the Convex).
+static int load_one(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* off, const int32_t* nbr,
+                    uint32_t cnv, const float* cpos, const uint32_t* coff, const int32_t* cnbr)
+{
+    const uint32_t mvo[2] = {0u, nv}, cvo[2] = {0u, cnv};
+    return surtr_load_fragments(ctx, 1, mvo, pos, off, nbr, cvo, cpos, coff, cnbr, nullptr);
+}
+
+int surtr_refit_solid(surtr_ctx* ctx, uint32_t mnv, const float* mpos, const uint32_t* moff, const int32_t* mnbr,
+                      uint32_t cnv, const float* cpos, const uint32_t* coff, const int32_t* cnbr,
+                      uint32_t* out_nv, uint32_t* out_nh, float* out_pos, uint32_t* out_off, int32_t* out_nbr)
+{
+    if (!ctx || !mpos || !moff || !mnbr || !cpos || !coff || !cnbr || mnv < 4 || cnv < 4) return SURTR_E_INVALID;
+    int rc = load_one(ctx, mnv, mpos, moff, mnbr, cnv, cpos, coff, cnbr);
+    if (rc) return rc;
+    rc = surtr_event_refit(ctx);
+    if (rc) return rc;
+    surtr_counts c;
+    rc = surtr_event_counts(ctx, &c);
+    if (rc) return rc;
+    if (out_nv) *out_nv = c.conv_verts;
+    if (out_nh) *out_nh = c.conv_nbrs;
+    if (!out_pos && !out_off && !out_nbr) return SURTR_OK;
+    std::vector<uint32_t> cvo(2);
+    surtr_fragments fr; memset(&fr, 0, sizeof(fr));
+    fr.conv_vert_off = cvo.data(); fr.conv_pos = out_pos; fr.conv_nbr_off = out_off; fr.conv_nbr = out_nbr;
+    return surtr_event_download(ctx, &fr);
+}
+
+int surtr_extract_faces(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* off, const int32_t* nbr,
+                        uint32_t* n_faces, uint32_t* n_face_idx, uint32_t* face_off, int32_t* face_idx)
+{
+    if (!ctx || !pos || !off || !nbr || nv < 4) return SURTR_E_INVALID;
+    int rc = load_one(ctx, nv, pos, off, nbr, nv, pos, off, nbr);
+    if (rc) return rc;
+    const uint32_t H = off[nv];
+    uint32_t *d_n = nullptr, *d_off = nullptr; int32_t* d_idx = nullptr;
+    auto cleanup = [&]() { free_dev(d_n); free_dev(d_off); free_dev(d_idx); };
+    if (hipMalloc((void**)&d_n, 16) != hipSuccess || hipMalloc((void**)&d_off, ((size_t)H + 2) * 4) != hipSuccess ||
+        hipMalloc((void**)&d_idx, ((size_t)ctx->fs.HF + 2) * 4) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
+    (void)hipMemsetAsync(d_n, 0, 16, ctx->stream);
+    rc = launch_faces(ctx, 0u, d_n, d_off, d_idx);
+    surtr_counts c;
+    if (rc == 0) rc = surtr_event_counts(ctx, &c);
+    uint32_t cnt[2] = {0u, 0u};
+    if (rc == 0 && hipMemcpy(cnt, d_n, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = SURTR_E_HIP;
+    if (rc == 0 && c.n_failed != 0) rc = SURTR_E_TOPOLOGY;       // the reference's walk never ends on this solid
+    if (rc == 0)
+    {
+        if (n_faces) *n_faces = cnt[0];
+        if (n_face_idx) *n_face_idx = cnt[1];
+        if (face_off && hipMemcpy(face_off, d_off, ((size_t)cnt[0] + 1) * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SURTR_E_HIP;
+        if (rc == 0 && face_idx && cnt[1] && hipMemcpy(face_idx, d_idx, (size_t)cnt[1] * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = SURTR_E_HIP;
+    }
+    cleanup();
+    return rc;
+}
+
+int surtr_triangulate(surtr_ctx* ctx, uint32_t nv, const float* pos, const uint32_t* off, const int32_t* nbr, int is_convex,
+                      const float color[3], float* vnc, uint32_t* n_idx, uint32_t* idx)
+{
+    if (!ctx || !pos || !off || !nbr || nv < 4) return SURTR_E_INVALID;
+    int rc = load_one(ctx, nv, pos, off, nbr, nv, pos, off, nbr);
+    if (rc) return rc;
+    rc = launch_faces(ctx, is_convex ? 1u : 0u, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    surtr_counts c;
+    rc = surtr_event_counts(ctx, &c);
+    if (rc) return rc;
+    if (c.n_failed != 0) return SURTR_E_TOPOLOGY;
+    if (n_idx) *n_idx = c.n_idx;
+    if (!vnc && !idx) return SURTR_OK;
+    for (int k = 0; k < 3; ++k) ctx->color[k] = color ? color[k] : 0.25f;
+    std::vector<uint32_t> io(2);
+    surtr_fragments fr; memset(&fr, 0, sizeof(fr));
+    fr.vnc = vnc; fr.idx_off = io.data(); fr.idx = idx;
+    rc = surtr_event_download(ctx, &fr);
+    for (int k = 0; k < 3; ++k) ctx->color[k] = 0.25f;
+    return rc;
 }
 
 int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts)
@@ -2839,7 +2662,7 @@ int surtr_event_counts(surtr_ctx* ctx, surtr_counts* counts)
     (void)hipSetDevice(ctx->device);
     HIPCHK(hipMemcpyAsync(&ctx->last, ctx->d_counts, sizeof(surtr_counts), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    *counts = ctx->last;
+    *counts = ctx->last; ctx->last_current = true;
     return ctx->last.status ? (int)ctx->last.status : SURTR_OK;
 }
 
@@ -2865,12 +2688,15 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
     if (!ctx || !dev_blob) return SURTR_E_INVALID;
     if (!ctx->have_event) return SURTR_E_STATE;
     (void)hipSetDevice(ctx->device);
-    // capacity is checked on the device against the counts it holds; the host check uses the last fetched counts if any
+    // capacity is checked on the device against the counts it holds (k_pack reports a blob that does not fit in its header
+    // and in the event's status word); when the host already holds this event's counts it refuses here
+    if (ctx->last_current && blob_layout(ctx->last).total > capacity) return SURTR_E_CAPACITY;
     const uint32_t grid = std::max(1u, std::min(ctx->cap_frags, 2048u));
     hipStream_t st = ctx->stream;
     PROF_BEGIN(5);
     hipLaunchKernelGGL(k_pack, dim3(grid), dim3(SURTR_WG), 0, ctx->stream, ctx->d_frags, ctx->d_counts, ctx->arena, (char*)dev_blob,
-                       capacity, (ctx->last_flags & SURTR_EVT_RENDER) ? 1u : 0u);
+                       capacity, (ctx->last_flags & SURTR_EVT_RENDER) ? 1u : 0u, ctx->d_frag_status,
+                       ctx->color[0], ctx->color[1], ctx->color[2]);
     PROF_END(5);
     HIPCHK(hipGetLastError());
     return SURTR_OK;
@@ -2954,6 +2780,7 @@ int surtr_blob_unpack_host(const void* blob, size_t bytes, surtr_counts* counts,
     cp(out->vnc, L.vnc, (size_t)c.mesh_verts * 36);
     cp(out->idx_off, L.ioff, ((size_t)c.n_frag + 1) * 4);
     cp(out->idx, L.idx, (size_t)c.n_idx * 4);
+    cp(out->frag_status, L.fstat, (size_t)c.n_frag * 4);
     return SURTR_OK;
 }
 

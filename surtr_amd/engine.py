@@ -24,13 +24,13 @@ class SurtrError(RuntimeError):
 
 class Counts(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
-                ("n_frag", "mesh_verts", "mesh_nbrs", "conv_verts", "conv_nbrs", "n_idx", "n_pairs", "status")]
+                ("n_frag", "mesh_verts", "mesh_nbrs", "conv_verts", "conv_nbrs", "n_idx", "n_pairs", "status", "n_failed")]
 
 
 class Fragments(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in
                 ("frag_ids", "mesh_vert_off", "mesh_pos", "mesh_nbr_off", "mesh_nbr", "conv_vert_off", "conv_pos",
-                 "conv_nbr_off", "conv_nbr", "vnc", "idx_off", "idx")]
+                 "conv_nbr_off", "conv_nbr", "vnc", "idx_off", "idx", "frag_status")]
 
 
 def lib_path():
@@ -73,6 +73,11 @@ def _strerror(code):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _solid_arrays(s):
+    return (np.ascontiguousarray(s["pos"], np.float32).reshape(-1, 3), np.ascontiguousarray(s["off"], np.uint32),
+            np.ascontiguousarray(s["nbr"], np.int32))
 
 
 def pack_solids(solids):
@@ -215,6 +220,66 @@ class Engine:
         self._ck(lib().surtr_event_download(self._h, ctypes.byref(fr)))
         return shape_fragments(out)
 
+    def load_fragments(self, meshes, convexes, frag_ids=None):
+        """surtr_load_fragments: host pieces presented as the fragments of an event."""
+        m = pack_solids(meshes)
+        c = pack_solids(convexes)
+        ids = None if frag_ids is None else np.ascontiguousarray(frag_ids, np.int32)
+        self._ck(lib().surtr_load_fragments(self._h, ctypes.c_uint32(len(meshes)), _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]),
+                                            _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(ids)))
+
+    def event_triangulate(self, is_convex=False):
+        self._ck(lib().surtr_event_triangulate(self._h, ctypes.c_int(int(is_convex))))
+
+    def refit_solid(self, mesh, convex):
+        """m_refittingTask for one Piece (surtr_refit_solid) -> the refitted Convex."""
+        mp, mo, mn = _solid_arrays(mesh)
+        cp, co, cn = _solid_arrays(convex)
+        nv, nh = ctypes.c_uint32(), ctypes.c_uint32()
+        args = [self._h, ctypes.c_uint32(mp.shape[0]), _p(mp), _p(mo), _p(mn), ctypes.c_uint32(cp.shape[0]), _p(cp), _p(co), _p(cn)]
+        self._ck(lib().surtr_refit_solid(*args, ctypes.byref(nv), ctypes.byref(nh), None, None, None))
+        opos = np.zeros((nv.value, 3), np.float32); ooff = np.zeros(nv.value + 1, np.uint32); onbr = np.zeros(nh.value, np.int32)
+        self._ck(lib().surtr_refit_solid(*args, ctypes.byref(nv), ctypes.byref(nh), _p(opos), _p(ooff), _p(onbr)))
+        return {"pos": opos, "off": ooff, "nbr": onbr}
+
+    def extract_faces(self, solid):
+        """Poly::ExtractFaces (surtr_extract_faces) -> (face_off, face_idx)."""
+        p, o, n = _solid_arrays(solid)
+        nf, ni = ctypes.c_uint32(), ctypes.c_uint32()
+        args = [self._h, ctypes.c_uint32(p.shape[0]), _p(p), _p(o), _p(n)]
+        self._ck(lib().surtr_extract_faces(*args, ctypes.byref(nf), ctypes.byref(ni), None, None))
+        fo = np.zeros(nf.value + 1, np.uint32); fi = np.zeros(ni.value, np.int32)
+        self._ck(lib().surtr_extract_faces(*args, ctypes.byref(nf), ctypes.byref(ni), _p(fo), _p(fi)))
+        return fo, fi
+
+    def triangulate(self, solid, is_convex=False, color=None):
+        """Poly::ExtractFaces + Poly::RenderPolyhedron (surtr_triangulate) -> (vnc f32[n,9], idx u32[...])."""
+        p, o, n = _solid_arrays(solid)
+        col = None if color is None else np.ascontiguousarray(color, np.float32)
+        ni = ctypes.c_uint32()
+        args = [self._h, ctypes.c_uint32(p.shape[0]), _p(p), _p(o), _p(n), ctypes.c_int(int(is_convex)), _p(col)]
+        self._ck(lib().surtr_triangulate(*args, None, ctypes.byref(ni), None))
+        vnc = np.zeros((p.shape[0], 9), np.float32); idx = np.zeros(ni.value, np.uint32)
+        self._ck(lib().surtr_triangulate(*args, _p(vnc), ctypes.byref(ni), _p(idx)))
+        return vnc, idx
+
+    def transform_pieces(self, world):
+        """Poly::Transform of every resident piece (surtr_transform_pieces); world: f32[n,4,4] row-major XMMATRIX."""
+        w = np.ascontiguousarray(world, np.float32).reshape(-1, 16)
+        self._ck(lib().surtr_transform_pieces(self._h, ctypes.c_uint32(w.shape[0]), _p(w)))
+
+    def pieces_from_event(self, keep=None):
+        """surtr_pieces_from_event: the last event's fragments become the resident pieces; returns their number."""
+        k = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        n = ctypes.c_uint32()
+        self._ck(lib().surtr_pieces_from_event(self._h, _p(k), ctypes.byref(n)))
+        return n.value
+
+    def upload_stats(self):
+        ms, na = ctypes.c_float(), ctypes.c_uint32()
+        self._ck(lib().surtr_upload_stats(self._h, ctypes.byref(ms), ctypes.byref(na)))
+        return float(ms.value), int(na.value)
+
     def clip_polyhedron(self, solid, planes):
         pos = np.ascontiguousarray(solid["pos"], np.float32).reshape(-1, 3)
         off = np.ascontiguousarray(solid["off"], np.uint32)
@@ -236,7 +301,8 @@ _FIELDS = [("frag_ids", np.int32, lambda c: 3 * c.n_frag), ("mesh_vert_off", np.
            ("mesh_nbr", np.int32, lambda c: c.mesh_nbrs), ("conv_vert_off", np.uint32, lambda c: c.n_frag + 1),
            ("conv_pos", np.float32, lambda c: 3 * c.conv_verts), ("conv_nbr_off", np.uint32, lambda c: c.conv_verts + 1),
            ("conv_nbr", np.int32, lambda c: c.conv_nbrs), ("vnc", np.float32, lambda c: 9 * c.mesh_verts),
-           ("idx_off", np.uint32, lambda c: c.n_frag + 1), ("idx", np.uint32, lambda c: c.n_idx)]
+           ("idx_off", np.uint32, lambda c: c.n_frag + 1), ("idx", np.uint32, lambda c: c.n_idx),
+           ("frag_status", np.uint32, lambda c: c.n_frag)]
 
 
 def alloc_fragments(c):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <random>
 #include <string>
 
@@ -46,9 +47,94 @@ static void make_torus(int nu, int nv, std::vector<Vector3>& v, std::vector<int>
     t.insert(t.end(), second.begin(), second.end());
 }
 
+// --api-dump FILE: runs the reference-named API (Poly::*, Kdop::*, VMACH::*) on fragments of the event and writes inputs and
+// results as JSON, so that a test can hold them against the oracle (tests/test_gpu_parity.py::test_cpp_api_surface).
+static void js_solid(FILE* f, const char* name, const Poly::Polyhedron& p)
+{
+    fprintf(f, "\"%s\": {\"pos\": [", name);
+    for (size_t i = 0; i < p.size(); ++i) fprintf(f, "%s%.9g, %.9g, %.9g", i ? ", " : "", p[i].Position.x, p[i].Position.y, p[i].Position.z);
+    fprintf(f, "], \"off\": [0");
+    size_t h = 0;
+    for (const auto& v : p) { h += v.NeighborVertexVec.size(); fprintf(f, ", %zu", h); }
+    fprintf(f, "], \"nbr\": [");
+    bool first = true;
+    for (const auto& v : p) for (int a : v.NeighborVertexVec) { fprintf(f, "%s%d", first ? "" : ", ", a); first = false; }
+    fprintf(f, "]}");
+}
+
+static void api_dump(const char* path, const std::vector<Fragment>& frags, const std::vector<VMACH::Polygon3D>& cells,
+                     const Vector3& ext, const Vector3& cen)
+{
+    FILE* f = fopen(path, "w");
+    if (!f) throw Error(SURTR_E_INVALID, std::string("cannot open ") + path);
+    fprintf(f, "{\"cases\": [");
+    for (size_t k = 0; k < frags.size() && k < 4; ++k)
+    {
+        const Piece& pc = frags[k].piece_data;
+        fprintf(f, "%s{", k ? ", " : "");
+        js_solid(f, "mesh", pc.Mesh); fprintf(f, ", "); js_solid(f, "convex", pc.Convex);
+        // Poly::ExtractFaces
+        Poly::Extract* ex = Poly::ExtractFaces(pc.Mesh);
+        fprintf(f, ", \"faces\": [");
+        for (size_t i = 0; i < ex->size(); ++i) { fprintf(f, "%s[", i ? ", " : ""); for (size_t j = 0; j < (*ex)[i].size(); ++j) fprintf(f, "%s%d", j ? ", " : "", (*ex)[i][j]); fprintf(f, "]"); }
+        fprintf(f, "]");
+        // Poly::RenderPolyhedron, appended after one dummy vertex to exercise the vertex offset (Src/Poly.cpp:688, 700-712)
+        for (int convex = 0; convex < 2; ++convex)
+        {
+            std::vector<VertexNormalColor> vd(1); std::vector<uint32_t> id;
+            const Poly::Polyhedron& solid = convex ? pc.Convex : pc.Mesh;
+            Poly::Extract* e2 = Poly::ExtractFaces(solid);
+            Poly::RenderPolyhedron(vd, id, solid, e2, convex != 0, Vector3(0.5f, 0.25f, 1.f));
+            delete e2;
+            fprintf(f, ", \"%s\": {\"nv\": %zu, \"idx\": [", convex ? "render_convex" : "render_mesh", vd.size());
+            for (size_t i = 0; i < id.size(); ++i) fprintf(f, "%s%u", i ? ", " : "", id[i]);
+            fprintf(f, "], \"color\": [%.9g, %.9g, %.9g]}", vd.back().Color[0], vd.back().Color[1], vd.back().Color[2]);
+        }
+        delete ex;
+        // m_refittingTask spelled with the reference's names (Src/Surtr.cpp:1449-1455)
+        {
+            std::vector<Vector3> pts; for (const auto& v : pc.Mesh) pts.push_back(v.Position);
+            Kdop::KdopContainer kdop(GenerateICHNormal(pts, (int)std::min<size_t>(pc.Mesh.size(), 4)));
+            kdop.Calc(pc.Mesh);
+            fprintf(f, ", "); js_solid(f, "refit_kdop", kdop.ClipWithPolyhedron(pc.Convex));
+            fprintf(f, ", "); js_solid(f, "refit_task", DefaultEngine().RefitSolid(pc.Mesh, pc.Convex));
+        }
+        // Poly::Moments, Poly::Transform
+        double vol = 0; Vector3 c1;
+        Poly::Moments(vol, c1, pc.Mesh);
+        fprintf(f, ", \"volume\": %.17g, \"centroid\": [%.9g, %.9g, %.9g]", vol, c1.x, c1.y, c1.z);
+        Matrix w; const float W[16] = {0.f, -1.25f, 0.f, 0.5f, 1.25f, 0.f, 0.f, -1.f, 0.f, 0.f, 1.25f, 2.f, 0.f, 0.f, 0.f, 1.f};
+        for (int i = 0; i < 16; ++i) w.m[i] = W[i];
+        Poly::Polyhedron moved = pc.Mesh;
+        Poly::Transform(moved, w);
+        fprintf(f, ", \"world\": [");
+        for (int i = 0; i < 16; ++i) fprintf(f, "%s%.9g", i ? ", " : "", W[i]);
+        fprintf(f, "], "); js_solid(f, "moved", moved);
+        fprintf(f, "}");
+    }
+    // Poly::ClipPolyhedron(polyhedron, polygon3D) on a placed GenerateVoronoi cell == the same clip with explicit planes
+    fprintf(f, "], \"cell_clip\": [");
+    for (size_t c = 0; c < cells.size() && c < 3; ++c)
+    {
+        VMACH::Polygon3D cell = cells[c];
+        cell.Scale(ext); cell.Translate(cen);
+        Poly::Polyhedron box = Poly::GetBB();
+        Poly::Scale(box, ext); Poly::Translate(box, cen);
+        const Poly::Polyhedron a = Poly::ClipPolyhedron(box, cell);
+        std::vector<Plane> planes; for (const auto& face : cell.FaceVec) planes.push_back(face.FacePlane);
+        Poly::Polyhedron b = box; Poly::ClipPolyhedron(b, planes);
+        fprintf(f, "%s{", c ? ", " : ""); js_solid(f, "by_polygon", a); fprintf(f, ", "); js_solid(f, "by_planes", b);
+        fprintf(f, ", \"planes\": [");
+        for (size_t i = 0; i < planes.size(); ++i) fprintf(f, "%s%.9g, %.9g, %.9g, %.9g", i ? ", " : "", planes[i].x, planes[i].y, planes[i].z, planes[i].w);
+        fprintf(f, "], "); js_solid(f, "box", box); fprintf(f, "}");
+    }
+    fprintf(f, "]}\n");
+    fclose(f);
+}
+
 int main(int argc, char** argv)
 {
-    std::string mesh = "cube", obj, obj_in;
+    std::string mesh = "cube", obj, obj_in, dump;
     int cells = 8, nu = 250, nv = 200;
     bool ach = false; float in_scale = 1.f;
     for (int i = 1; i < argc; ++i)
@@ -61,6 +147,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--obj-in") && i + 1 < argc) { obj_in = argv[++i]; mesh = obj_in; }
         else if (!strcmp(argv[i], "--scale") && i + 1 < argc) in_scale = (float)atof(argv[++i]);
         else if (!strcmp(argv[i], "--ach")) ach = true;
+        else if (!strcmp(argv[i], "--api-dump") && i + 1 < argc) dump = argv[++i];
     }
     try
     {
@@ -94,6 +181,7 @@ int main(int argc, char** argv)
             eng.SetCompound(comp);
             frags = eng.ApplyFracture();
         }
+        if (!dump.empty()) api_dump(dump.c_str(), frags, FractureEngine::GenerateVoronoi(seeds), ext, cen);
         const surtr_counts c = eng.LastCounts();
         printf("{\"mesh\": \"%s\", \"verts\": %zu, \"tris\": %zu, \"cells\": %d, \"fragments\": %u, \"mesh_verts\": %u, \"mesh_nbrs\": %u, "
                "\"conv_verts\": %u, \"indices\": %u}\n", mesh.c_str(), verts.size(), tris.size() / 3, cells, c.n_frag, c.mesh_verts,

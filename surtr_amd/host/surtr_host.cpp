@@ -35,10 +35,160 @@ Poly::Polyhedron rebuild(const float* pos, const uint32_t* off, const int32_t* n
 }
 } // namespace
 
+namespace {
+int g_default_device = 0;
+std::vector<Plane> planes_of(const std::vector<float>& pl)
+{
+    std::vector<Plane> out(pl.size() / 4);
+    for (size_t i = 0; i < out.size(); ++i) out[i] = Plane(pl[4 * i], pl[4 * i + 1], pl[4 * i + 2], pl[4 * i + 3]);
+    return out;
+}
+std::vector<float> flat_points(const std::vector<Vector3>& v)
+{
+    std::vector<float> pts; pts.reserve(3 * v.size());
+    for (const auto& p : v) { pts.push_back(p.x); pts.push_back(p.y); pts.push_back(p.z); }
+    return pts;
+}
+} // namespace
+
+void SetDefaultDevice(int device) { g_default_device = device; }
+FractureEngine& DefaultEngine()
+{
+    static FractureEngine engine(g_default_device);
+    return engine;
+}
+
+// ---- VMACH: the cell container ------------------------------------------------------------------------------------
+Plane VMACH::ConstructFacePlane(const PolygonFace& f)
+{
+    if (f.VertexVec.size() < 3) throw Error(SURTR_E_INVALID, "ConstructFacePlane: face with fewer than 3 vertices");
+    const float a[3] = {f.VertexVec[0].x, f.VertexVec[0].y, f.VertexVec[0].z}, b[3] = {f.VertexVec[1].x, f.VertexVec[1].y, f.VertexVec[1].z},
+                c[3] = {f.VertexVec[2].x, f.VertexVec[2].y, f.VertexVec[2].z};
+    float pl[4];
+    surtr_plane_from_points(a, b, c, pl);
+    return Plane(pl[0], pl[1], pl[2], pl[3]);
+}
+void VMACH::PolygonFace::ConstructFacePlane()
+{
+    if (GuaranteeConvex && VertexVec.size() >= 3) { FacePlane = VMACH::ConstructFacePlane(*this); FacePlaneConstructed = true; }
+}
+void VMACH::PolygonFace::AddVertex(const Vector3& v)
+{
+    // NearlyEqual: (v1 - v2).Length() < 1e-12 on floats, i.e. practically exact equality (Src/VMACH.cpp:1205, Inc/pch.h:18)
+    for (const auto& o : VertexVec)
+    {
+        const float dx = o.x - v.x, dy = o.y - v.y, dz = o.z - v.z;
+        if ((double)(dx * dx + dy * dy + dz * dz) < 1e-24) return;
+    }
+    VertexVec.push_back(v);
+    if (GuaranteeConvex && VertexVec.size() == 3) ConstructFacePlane();
+}
+Vector3 VMACH::PolygonFace::GetNormal() const
+{
+    if (!FacePlaneConstructed) throw Error(SURTR_E_STATE, "PolygonFace::GetNormal: the face plane was never built (Src/VMACH.cpp:88-97)");
+    return Vector3(FacePlane.x, FacePlane.y, FacePlane.z);      // already unit length
+}
+void VMACH::Polygon3D::Translate(const Vector3& t)
+{
+    for (auto& f : FaceVec) { for (auto& v : f.VertexVec) { v.x += t.x; v.y += t.y; v.z += t.z; } f.ConstructFacePlane(); }
+}
+void VMACH::Polygon3D::Scale(const Vector3& s)
+{
+    for (auto& f : FaceVec) { for (auto& v : f.VertexVec) { v.x *= s.x; v.y *= s.y; v.z *= s.z; } f.ConstructFacePlane(); }
+}
+
+// ---- Poly: free functions with the reference's signatures, on the default engine -------------------------------------
 void Poly::InitPolyhedron(Polyhedron& polyhedron, const std::vector<Vector3>& positionVec, const std::vector<std::vector<int>>& neighborVec)
 {
     polyhedron.resize(positionVec.size());
     for (size_t i = 0; i < positionVec.size(); ++i) { polyhedron[i].Position = positionVec[i]; polyhedron[i].NeighborVertexVec = neighborVec[i]; }
+}
+
+void Poly::Moments(double& zerothMoment, Vector3& firstMoment, const Polyhedron& polyhedron)
+{
+    Flat in; in.add(polyhedron);
+    float cen[3] = {0, 0, 0};
+    const int rc = surtr_moments((uint32_t)polyhedron.size(), in.pos.data(), in.nbr_off.data(), in.nbr.data(), &zerothMoment, cen);
+    if (rc) throw Error(rc, std::string("Moments: ") + surtr_strerror(rc));
+    firstMoment = Vector3(cen[0], cen[1], cen[2]);
+}
+
+Poly::Extract* Poly::ExtractFaces(const Polyhedron& polyhedron) { return new Extract(DefaultEngine().ExtractFaces(polyhedron)); }
+
+void Poly::ClipPolyhedron(Polyhedron& polyhedron, const std::vector<Plane>& planes)
+{
+    if (polyhedron.empty()) return;
+    polyhedron = DefaultEngine().ClipPolyhedron(polyhedron, planes);
+}
+Poly::Polyhedron Poly::ClipPolyhedron(const Polyhedron& polyhedron, const VMACH::Polygon3D& polygon3D)
+{
+    return DefaultEngine().ClipPolyhedron(polyhedron, polygon3D);
+}
+void Poly::Transform(Polyhedron& polyhedron, const Matrix& matrix) { polyhedron = DefaultEngine().TransformSolid(polyhedron, matrix); }
+
+void Poly::RenderPolyhedron(std::vector<VertexNormalColor>& vertexData, std::vector<uint32_t>& indexData, const Polyhedron& poly,
+                            const Extract* extract, bool isConvex, Vector3 color)
+{
+    (void)extract;      // == ExtractFaces(poly): the kernels derive the face loops themselves
+    const FragmentRender r = DefaultEngine().RenderPolyhedron(poly, isConvex, color);
+    const uint32_t vertexOffset = (uint32_t)vertexData.size();
+    vertexData.insert(vertexData.end(), r.vertexData.begin(), r.vertexData.end());
+    for (uint32_t i : r.indexData) indexData.push_back(vertexOffset + i);
+}
+
+// ---- Kdop ------------------------------------------------------------------------------------------------------------
+Kdop::KdopContainer::KdopContainer(const std::vector<Vector3>& normalVec)
+{
+    for (const auto& n : normalVec) ElementVec.emplace_back(n);
+}
+namespace {
+void fill_kdop(Kdop::KdopContainer& K, const std::vector<float>& pts, bool ach, double maxAxisScale, float planeGapInv)
+{
+    const uint32_t k = (uint32_t)K.ElementVec.size(), n = (uint32_t)(pts.size() / 3);
+    if (k == 0 || n == 0) return;
+    std::vector<float> nrm, pl(8 * (size_t)k);
+    for (const auto& e : K.ElementVec) { nrm.push_back(e.Normal.x); nrm.push_back(e.Normal.y); nrm.push_back(e.Normal.z); }
+    const int rc = ach ? surtr_kdop_ach_planes(n, pts.data(), k, nrm.data(), maxAxisScale, planeGapInv, pl.data())
+                       : surtr_kdop_planes(n, pts.data(), k, nrm.data(), pl.data());
+    if (rc) throw Error(rc, std::string("KdopContainer::Calc: ") + surtr_strerror(rc));
+    for (uint32_t j = 0; j < k; ++j)
+    {
+        K.ElementVec[j].MinPlane = Plane(pl[8 * j], pl[8 * j + 1], pl[8 * j + 2], pl[8 * j + 3]);
+        K.ElementVec[j].MaxPlane = Plane(pl[8 * j + 4], pl[8 * j + 5], pl[8 * j + 6], pl[8 * j + 7]);
+    }
+}
+} // namespace
+void Kdop::KdopContainer::Calc(const std::vector<Vector3>& vertices, const double& maxAxisScale, const float& planeGapInv)
+{
+    fill_kdop(*this, flat_points(vertices), true, maxAxisScale, planeGapInv);
+}
+void Kdop::KdopContainer::Calc(const Poly::Polyhedron& mesh)
+{
+    std::vector<float> pts;
+    for (const auto& v : mesh) { pts.push_back(v.Position.x); pts.push_back(v.Position.y); pts.push_back(v.Position.z); }
+    fill_kdop(*this, pts, false, 0.0, 1.f);
+}
+Poly::Polyhedron Kdop::KdopContainer::ClipWithPolyhedron(const Poly::Polyhedron& polyhedron)
+{
+    std::vector<Plane> planes;
+    for (const auto& e : ElementVec) { planes.push_back(e.MinPlane); planes.push_back(e.MaxPlane); }
+    Poly::Polyhedron res = polyhedron;
+    Poly::ClipPolyhedron(res, planes);
+    return res;
+}
+
+std::vector<Vector3> GenerateICHNormal(const std::vector<Vector3>& vertices, int limitCnt)
+{
+    const std::vector<float> pts = flat_points(vertices);
+    uint32_t k = 0;
+    int rc = surtr_hull_normals((uint32_t)vertices.size(), pts.data(), (uint32_t)limitCnt, 0, nullptr, &k);
+    if (rc) throw Error(rc, std::string("GenerateICHNormal: ") + surtr_strerror(rc));
+    std::vector<float> nrm(3 * (size_t)k + 3);
+    rc = surtr_hull_normals((uint32_t)vertices.size(), pts.data(), (uint32_t)limitCnt, k, nrm.data(), &k);
+    if (rc) throw Error(rc, std::string("GenerateICHNormal: ") + surtr_strerror(rc));
+    std::vector<Vector3> out(k);
+    for (uint32_t i = 0; i < k; ++i) out[i] = Vector3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]);
+    return out;
 }
 
 Poly::Polyhedron Poly::GetBB()
@@ -177,9 +327,10 @@ std::vector<VMACH::Polygon3D> FractureEngine::GenerateVoronoi(const std::vector<
     for (uint32_t c = 0; c < n; ++c)
         for (uint32_t f = cfo[c]; f < cfo[c + 1]; ++f)
         {
-            VMACH::PolygonFace face;
+            VMACH::PolygonFace face(true);
             for (uint32_t v = fvo[f]; v < fvo[f + 1]; ++v)
                 face.VertexVec.emplace_back((float)verts[3 * v], (float)verts[3 * v + 1], (float)verts[3 * v + 2]);
+            face.ConstructFacePlane();
             out[c].FaceVec.push_back(face);
         }
     return out;
@@ -211,14 +362,15 @@ std::vector<Fragment> FractureEngine::ApplyFracture(const std::set<int>& outside
     std::vector<int32_t> ids(3 * (size_t)c.n_frag), mnbr(c.mesh_nbrs), cnbr(c.conv_nbrs);
     std::vector<uint32_t> mvo(c.n_frag + 1), mno(c.mesh_verts + 1), cvo(c.n_frag + 1), cno(c.conv_verts + 1), ioff(c.n_frag + 1), idx(c.n_idx);
     std::vector<float> mpos(3 * (size_t)c.mesh_verts), cpos(3 * (size_t)c.conv_verts), vnc(9 * (size_t)c.mesh_verts);
+    std::vector<uint32_t> fstat(c.n_frag);
     surtr_fragments fr{ids.data(), mvo.data(), mpos.data(), mno.data(), mnbr.data(), cvo.data(), cpos.data(), cno.data(), cnbr.data(),
-                       vnc.data(), ioff.data(), idx.data()};
+                       vnc.data(), ioff.data(), idx.data(), fstat.data()};
     check(surtr_event_download(ctx_, &fr), "surtr_event_download");
     std::vector<Fragment> out(c.n_frag);
     for (uint32_t f = 0; f < c.n_frag; ++f)
     {
         Fragment& F = out[f];
-        F.cell = ids[3 * f]; F.piece = ids[3 * f + 1]; F.island = ids[3 * f + 2];
+        F.cell = ids[3 * f]; F.piece = ids[3 * f + 1]; F.island = ids[3 * f + 2]; F.status = (int)fstat[f];
         F.piece_data.Mesh = rebuild(mpos.data(), mno.data(), mnbr.data(), mvo[f], mvo[f + 1]);
         // rings are fragment-local already; offsets are global over the vertex array
         F.piece_data.Convex = rebuild(cpos.data(), cno.data(), cnbr.data(), cvo[f], cvo[f + 1]);
@@ -249,9 +401,108 @@ Poly::Polyhedron FractureEngine::ClipPolyhedron(const Poly::Polyhedron& polyhedr
 
 Poly::Polyhedron FractureEngine::ClipPolyhedron(const Poly::Polyhedron& polyhedron, const VMACH::Polygon3D& polygon3D)
 {
+    // The reference keeps PolygonFace::FacePlane current through ConstructFacePlane on AddVertex / Scale / Translate
+    // (Src/VMACH.cpp:302-310); this layer's PolygonFace is a plain struct, so the plane is rebuilt here from the first three
+    // vertices with the arithmetic of k_place_cells (Plane(p0,p1,p2), normalised: SimpleMath.inl:2773-2780).
     std::vector<Plane> planes;
-    for (const auto& f : polygon3D.FaceVec) planes.push_back(f.FacePlane);
+    for (const auto& f : polygon3D.FaceVec)
+    {
+        if (f.VertexVec.size() < 3) throw Error(SURTR_E_INVALID, "ClipPolyhedron: face with fewer than 3 vertices");
+        planes.push_back(VMACH::ConstructFacePlane(f));
+    }
     return ClipPolyhedron(polyhedron, planes);
+}
+
+void FractureEngine::TransformCompound(const std::vector<Matrix>& worldMatrices)
+{
+    if (worldMatrices.size() != n_pieces_) throw Error(SURTR_E_INVALID, "TransformCompound: one matrix per piece");
+    std::vector<float> w; w.reserve(16 * worldMatrices.size());
+    for (const auto& m : worldMatrices) w.insert(w.end(), m.m, m.m + 16);
+    check(surtr_transform_pieces(ctx_, n_pieces_, w.data()), "surtr_transform_pieces");
+}
+
+uint32_t FractureEngine::CompoundFromLastEvent(const std::vector<uint8_t>& keep)
+{
+    uint32_t n = 0;
+    check(surtr_pieces_from_event(ctx_, keep.empty() ? nullptr : keep.data(), &n), "surtr_pieces_from_event");
+    n_pieces_ = n;
+    return n;
+}
+
+void FractureEngine::Refitting(std::vector<Piece>& pieceVec)
+{
+    if (pieceVec.empty()) return;
+    Flat m, c;
+    for (const auto& p : pieceVec) { m.add(p.Mesh); c.add(p.Convex); }
+    const uint32_t n = (uint32_t)pieceVec.size();
+    check(surtr_load_fragments(ctx_, n, m.vert_off.data(), m.pos.data(), m.nbr_off.data(), m.nbr.data(),
+                               c.vert_off.data(), c.pos.data(), c.nbr_off.data(), c.nbr.data(), nullptr), "surtr_load_fragments");
+    check(surtr_event_refit(ctx_), "surtr_event_refit");
+    check(surtr_event_counts(ctx_, &counts_), "surtr_event_counts");
+    std::vector<uint32_t> cvo(n + 1), cno(counts_.conv_verts + 1);
+    std::vector<float> cpos(3 * (size_t)counts_.conv_verts + 3);
+    std::vector<int32_t> cnbr(counts_.conv_nbrs + 1);
+    surtr_fragments fr{};
+    fr.conv_vert_off = cvo.data(); fr.conv_pos = cpos.data(); fr.conv_nbr_off = cno.data(); fr.conv_nbr = cnbr.data();
+    check(surtr_event_download(ctx_, &fr), "surtr_event_download");
+    for (uint32_t k = 0; k < n; ++k) pieceVec[k].Convex = rebuild(cpos.data(), cno.data(), cnbr.data(), cvo[k], cvo[k + 1]);
+}
+
+Poly::Polyhedron FractureEngine::RefitSolid(const Poly::Polyhedron& mesh, const Poly::Polyhedron& convex)
+{
+    Flat m, c; m.add(mesh); c.add(convex);
+    uint32_t nv = 0, nh = 0;
+    const uint32_t MV = (uint32_t)mesh.size(), CV = (uint32_t)convex.size();
+    check(surtr_refit_solid(ctx_, MV, m.pos.data(), m.nbr_off.data(), m.nbr.data(), CV, c.pos.data(), c.nbr_off.data(), c.nbr.data(),
+                            &nv, &nh, nullptr, nullptr, nullptr), "surtr_refit_solid");
+    std::vector<float> pos(3 * (size_t)nv + 3); std::vector<uint32_t> off(nv + 1); std::vector<int32_t> nbr(nh + 1);
+    check(surtr_refit_solid(ctx_, MV, m.pos.data(), m.nbr_off.data(), m.nbr.data(), CV, c.pos.data(), c.nbr_off.data(), c.nbr.data(),
+                            &nv, &nh, pos.data(), off.data(), nbr.data()), "surtr_refit_solid");
+    return rebuild(pos.data(), off.data(), nbr.data(), 0, nv);
+}
+
+Poly::Extract FractureEngine::ExtractFaces(const Poly::Polyhedron& polyhedron)
+{
+    Flat in; in.add(polyhedron);
+    const uint32_t V = (uint32_t)polyhedron.size();
+    uint32_t nf = 0, ni = 0;
+    check(surtr_extract_faces(ctx_, V, in.pos.data(), in.nbr_off.data(), in.nbr.data(), &nf, &ni, nullptr, nullptr), "surtr_extract_faces");
+    std::vector<uint32_t> fo(nf + 1); std::vector<int32_t> fi(ni + 1);
+    check(surtr_extract_faces(ctx_, V, in.pos.data(), in.nbr_off.data(), in.nbr.data(), &nf, &ni, fo.data(), fi.data()), "surtr_extract_faces");
+    Poly::Extract out(nf);
+    for (uint32_t f = 0; f < nf; ++f) out[f].assign(fi.begin() + fo[f], fi.begin() + fo[f + 1]);
+    return out;
+}
+
+FragmentRender FractureEngine::RenderPolyhedron(const Poly::Polyhedron& poly, bool isConvex, const Vector3& color)
+{
+    Flat in; in.add(poly);
+    const uint32_t V = (uint32_t)poly.size();
+    const float col[3] = {color.x, color.y, color.z};
+    uint32_t ni = 0;
+    check(surtr_triangulate(ctx_, V, in.pos.data(), in.nbr_off.data(), in.nbr.data(), isConvex ? 1 : 0, col, nullptr, &ni, nullptr), "surtr_triangulate");
+    FragmentRender r;
+    r.vertexData.resize(V); r.indexData.resize(ni);
+    std::vector<uint32_t> idx(ni + 1);
+    check(surtr_triangulate(ctx_, V, in.pos.data(), in.nbr_off.data(), in.nbr.data(), isConvex ? 1 : 0, col, (float*)r.vertexData.data(), &ni, idx.data()),
+          "surtr_triangulate");
+    std::copy(idx.begin(), idx.begin() + ni, r.indexData.begin());
+    return r;
+}
+
+Poly::Polyhedron FractureEngine::TransformSolid(const Poly::Polyhedron& polyhedron, const Matrix& matrix)
+{
+    // the device path of Poly::Transform is surtr_transform_pieces on resident pieces; a lone host polyhedron goes there and back
+    Flat in; in.add(polyhedron);
+    check(surtr_upload_pieces(ctx_, 1, in.vert_off.data(), in.pos.data(), in.nbr_off.data(), in.nbr.data(),
+                              in.vert_off.data(), in.pos.data(), in.nbr_off.data(), in.nbr.data()), "surtr_upload_pieces");
+    n_pieces_ = 1;
+    check(surtr_transform_pieces(ctx_, 1, matrix.m), "surtr_transform_pieces");
+    uint32_t nv = 0, nh = 0;
+    check(surtr_download_piece(ctx_, 0, 0, &nv, &nh, nullptr, nullptr, nullptr), "surtr_download_piece");
+    std::vector<float> pos(3 * (size_t)nv + 3); std::vector<uint32_t> off(nv + 1); std::vector<int32_t> nbr(nh + 1);
+    check(surtr_download_piece(ctx_, 0, 0, &nv, &nh, pos.data(), off.data(), nbr.data()), "surtr_download_piece");
+    return rebuild(pos.data(), off.data(), nbr.data(), 0, nv);
 }
 
 } // namespace surtr

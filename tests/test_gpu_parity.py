@@ -119,7 +119,7 @@ def test_torus_4096_properties(torus_run, oracle):
     planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
     mvo, mno = got["mesh_vert_off"].astype(np.int64), got["mesh_nbr_off"].astype(np.int64)
     ioff = got["idx_off"].astype(np.int64)
-    for k in range(0, nf, 7):
+    for k in range(nf):
         fr = fragment(got, k)
         nv = fr["pos"].shape[0]
         off = fr["off"].astype(np.int64)
@@ -280,3 +280,151 @@ def test_degenerate_fragments_found_by_the_refracture_fuzz(gpu_engine, oracle, n
     ref = oracle.event([mesh], [conv], fo, d["planes"], refit=True, render=True, threads=2)
     assert c.status == 0
     assert_event_equal(got, ref)
+
+
+# ---- the per-Piece operators, device-resident pieces (tests/test_solid_ops.py holds the cases) ------------------------
+import test_solid_ops as _ops
+import test_regroup as _rg
+
+
+@pytest.mark.parametrize("case", _ops.CASES, ids=lambda f: f.__name__)
+def test_solid_ops_gpu(gpu_engine, oracle, case):
+    case(gpu_engine, oracle)
+
+
+def test_regroup_then_refit_on_a_two_level_torus_fracture(gpu_engine, oracle):
+    """Rows A13 / f1 on the GPU tier: cfg4's torus x 256 cells, its 234 fragments hit by a 32-cell pattern; bind sets,
+    HandleConvexIsland on the un-refitted Convex solids, then surtr_event_refit (Src/Surtr.cpp:1921-1939)."""
+    _rg.check_regroup_and_refit_order(gpu_engine, oracle, 256, 32, torus=True)
+
+
+def test_partial_fracture_of_the_torus_pieces(gpu_engine, oracle):
+    _rg.check_partial_fracture_merges_out_of_impact(gpu_engine, oracle, 256, 32, torus=True)
+
+
+def test_outside_mask_skips_pieces_gpu(gpu_engine, oracle):
+    sc = scenes.cube_scene(8)
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"], sc["mesh"]], [sc["convex"], sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    eng.fracture_event(0, 8, outside=[1, 0], flags=3)
+    got = eng.download()
+    eng.close()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]] * 2, [sc["convex"]] * 2, sc["face_off"], planes, outside=[1, 0])
+    assert np.all(got["frag_ids"][:, 1] == 1)
+    assert_event_equal(got, ref)
+
+
+def test_errors_are_reported_on_the_gpu(gpu_engine):
+    sc = scenes.blob_scene(64)
+    # bad topology: refused by the device-side link check of the upload
+    bad = dict(sc["mesh"], nbr=sc["mesh"]["nbr"].copy())
+    bad["nbr"][0] = (bad["nbr"][0] + 3) % 8
+    eng = gpu_engine.Engine(0)
+    with pytest.raises(gpu_engine.SurtrError) as e:
+        eng.upload_pieces([bad], [sc["convex"]])
+    assert e.value.code == gpu_engine.E_TOPOLOGY
+    with pytest.raises(gpu_engine.SurtrError) as e:
+        eng.fracture_event(0, 1)
+    assert e.value.code == gpu_engine.E_STATE
+    # arena too small: SURTR_E_CAPACITY, and the context keeps working once the arena is back
+    eng.set_arena(64, 256, 256)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.upload_pattern(sc["face_off"], sc["v012"])
+    eng.place_cells(sc["scale"], sc["translate"])
+    with pytest.raises(gpu_engine.SurtrError) as e:
+        eng.fracture_event(0, 64)
+    assert e.value.code == gpu_engine.E_CAPACITY
+    eng.set_arena(0, 0, 0)
+    c = eng.fracture_event(0, 64)
+    assert c.status == 0 and c.n_frag == 48
+    # a blob buffer that is too small: refused on the host when the counts are known, flagged in the header otherwise
+    import torch
+    small = torch.zeros(4096, dtype=torch.uint8, device="cuda:0")
+    with pytest.raises(gpu_engine.SurtrError) as e:
+        eng.pack_dev(small.data_ptr(), 4096)
+    assert e.value.code == gpu_engine.E_CAPACITY
+    eng.fracture_event_async(0, 64)
+    eng.pack_dev(small.data_ptr(), 4096)
+    torch.cuda.synchronize()
+    hdr = np.frombuffer(small.cpu().numpy()[:36].tobytes(), np.uint32)
+    assert hdr[0] == 0 and hdr[7] == gpu_engine.E_CAPACITY
+    with pytest.raises(gpu_engine.SurtrError) as e:
+        eng.event_counts()
+    assert e.value.code == gpu_engine.E_CAPACITY
+    eng.close()
+
+
+def test_image_arena_exhaustion_on_the_torus(gpu_engine, oracle, torus_run, monkeypatch):
+    """k_prep_pairs runs out of image room after a few dozen pairs: the rest is pre-passed by k_clip_pairs itself."""
+    monkeypatch.setenv("SURTR_IMG_BYTES", str(8 << 20))
+    sc, c0, got0, ref = torus_run
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+    c = eng.fracture_event(0, 1024, flags=3)
+    got = eng.download()
+    qs = eng.queue_stats()
+    eng.close()
+    assert c.status == 0 and qs[16 + 13] > 0, "no pair was left without an image"
+    n = c.n_frag
+    assert np.array_equal(got["frag_ids"], ref["frag_ids"][:n]) and np.array_equal(got["mesh_nbr"], ref["mesh_nbr"][:c.mesh_nbrs])
+    assert np.array_equal(got["idx"], ref["idx"][:c.n_idx])
+
+
+def test_torus_4096_repeat_run_digest(gpu_engine, torus_run):
+    """The arena is filled in arrival order (atomics): three more runs of the whole cfg4 event give the same blob."""
+    sc, c0, got0, ref = torus_run
+    want = json.load(open(os.path.join(HERE, "digests.json")))["torus4096"]
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+    for _ in range(3):
+        eng.fracture_event(0, 4096, flags=3)
+        got = eng.download()
+        for k in TOPO:
+            assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == want[k], k
+        assert np.array_equal(got["mesh_pos"], got0["mesh_pos"])
+    eng.close()
+
+
+def test_cpp_api_surface(gpu_engine, oracle):
+    """The reference-named C++ API (Poly::ExtractFaces / RenderPolyhedron / Transform / Moments / ClipPolyhedron(polygon3D),
+    Kdop::KdopContainer, GenerateICHNormal) through the harness, every result held against the oracle."""
+    import json as js
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "surtr_amd", "host")])
+    exe = os.path.join(root, "surtr_amd", "host", "surtr_harness")
+    with tempfile.TemporaryDirectory() as d:
+        dump = os.path.join(d, "api.json")
+        subprocess.check_output([exe, "--mesh", "torus", "--cells", "64", "--nu", "60", "--nv", "36", "--api-dump", dump])
+        data = js.load(open(dump))
+
+    def solid(j):
+        return {"pos": np.array(j["pos"], np.float32).reshape(-1, 3), "off": np.array(j["off"], np.uint32), "nbr": np.array(j["nbr"], np.int32)}
+
+    def same(a, b):
+        assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"])
+        assert np.allclose(a["pos"], b["pos"], rtol=RTOL, atol=1e-6)
+    assert len(data["cases"]) == 4
+    for case in data["cases"]:
+        mesh, conv = solid(case["mesh"]), solid(case["convex"])
+        fo, fi = oracle.extract_faces(mesh)
+        assert [fi[fo[i]:fo[i + 1]].tolist() for i in range(len(fo) - 1)] == case["faces"]
+        for key, s, cv in (("render_mesh", mesh, False), ("render_convex", conv, True)):
+            rv, ri = oracle.render(s, convex=cv, colour=(0.5, 0.25, 1.0))
+            assert case[key]["nv"] == s["pos"].shape[0] + 1                       # appended after the vertex already there
+            assert (np.array(case[key]["idx"], np.int64) - 1).tolist() == ri.tolist()
+            assert case[key]["color"] == [0.5, 0.25, 1.0]
+        ref = oracle.refit(conv, mesh, 4)
+        same(solid(case["refit_task"]), ref)
+        same(solid(case["refit_kdop"]), ref)                                       # the task spelled with Kdop::KdopContainer
+        vol, cen = oracle.moments(mesh)
+        assert abs(case["volume"] - vol) <= 1e-9 * abs(vol) and np.allclose(case["centroid"], cen, rtol=1e-6, atol=1e-7)
+        same(solid(case["moved"]), _ops.transform_ref(mesh, np.array(case["world"], np.float32).reshape(4, 4)))
+    for cc in data["cell_clip"]:
+        same(solid(cc["by_polygon"]), solid(cc["by_planes"]))
+        same(solid(cc["by_polygon"]), oracle.clip(solid(cc["box"]), np.array(cc["planes"], np.float32).reshape(-1, 4)))
+        assert solid(cc["by_polygon"])["pos"].shape[0] >= 4

@@ -7,9 +7,9 @@ from helpers import assert_event_equal
 from surtr_amd import meshgen, scenes
 
 
-def _two_level(engine_mod, n_first, n_second):
-    """First event on a blob -> its fragments become the pieces of one compound hit by a second pattern."""
-    sc = scenes.blob_scene(n_first)
+def _two_level(engine_mod, n_first, n_second, torus=False):
+    """First event on a blob (or the cfg4 torus) -> its fragments become the pieces of one compound hit by a second pattern."""
+    sc = scenes.torus_scene(n_first) if torus else scenes.blob_scene(n_first)
     eng = engine_mod.Engine(0)
     eng.upload_pieces([sc["mesh"]], [sc["convex"]])
     eng.upload_pattern(sc["face_off"], sc["v012"])
@@ -36,17 +36,17 @@ def _solids(ev, pre):
     return out
 
 
-def test_regroup_and_refit_order(emul_engine, oracle):
-    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, 24, 5)
+def check_regroup_and_refit_order(emul_engine, oracle, n_first=24, n_second=5, torus=False):
+    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, n_first, n_second, torus)
     # event WITHOUT refit: the reference regroups on the un-refitted Convex solids
-    c = eng.fracture_event(0, 5, flags=2)
+    c = eng.fracture_event(0, n_second, flags=2)
     ev = eng.download()
     conv = _solids(ev, "conv")
     assert c.n_frag > 20
     co, cp = emul_engine.regroup(conv, ev["frag_ids"][:, 0])
     ro, rp = oracle.regroup(conv, ev["frag_ids"][:, 0])
     assert np.array_equal(co, ro) and np.array_equal(cp, rp)
-    assert co.shape[0] - 1 >= 6           # bind 0 + one compound per cell (+ splits)
+    assert co.shape[0] - 1 >= n_second + 1           # bind 0 + one compound per cell (+ splits)
     assert sorted(cp.tolist()) == list(range(c.n_frag))
     # islands of compounds were actually found somewhere (pieces of one cell that do not touch)
     sizes = np.diff(co.astype(np.int64))
@@ -60,8 +60,8 @@ def test_regroup_and_refit_order(emul_engine, oracle):
     eng.close()
 
 
-def test_partial_fracture_merges_out_of_impact(emul_engine, oracle):
-    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, 24, 5)
+def check_partial_fracture_merges_out_of_impact(emul_engine, oracle, n_first=24, n_second=5, torus=False):
+    sc, eng, meshes, convexes, fo, v012 = _two_level(emul_engine, n_first, n_second, torus)
     sphere, _ = meshgen.icosphere(2)
     impact = (sc["translate"] + np.float32([0.2, 0.1, 0.0]) * sc["scale"]).astype(np.float32)
     radius = float(0.2 * sc["scale"].max())
@@ -70,7 +70,7 @@ def test_partial_fracture_merges_out_of_impact(emul_engine, oracle):
     outside = np.array([emul_engine.convex_out_of_sphere(cv, cloud, impact, radius) for cv in convexes], np.uint8)
     assert all(bool(outside[i]) == oracle.convex_out_of_sphere(convexes[i], cloud, impact, radius) for i in range(len(convexes)))
     assert 0 < outside.sum() < len(convexes)
-    c = eng.fracture_event(0, 5, outside=outside, flags=2)
+    c = eng.fracture_event(0, n_second, outside=outside, flags=2)
     ev = eng.download()
     assert not np.isin(ev["frag_ids"][:, 1], np.nonzero(outside)[0]).any()
     pieces = [convexes[i] for i in np.nonzero(outside)[0]] + _solids(ev, "conv")
@@ -81,3 +81,11 @@ def test_partial_fracture_merges_out_of_impact(emul_engine, oracle):
     assert np.array_equal(co, ro) and np.array_equal(cp, rp)
     assert np.diff(co.astype(np.int64))[0] >= n_out          # the outside compound only grows
     eng.close()
+
+
+def test_regroup_and_refit_order(emul_engine, oracle):
+    check_regroup_and_refit_order(emul_engine, oracle)
+
+
+def test_partial_fracture_merges_out_of_impact(emul_engine, oracle):
+    check_partial_fracture_merges_out_of_impact(emul_engine, oracle)
