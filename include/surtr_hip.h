@@ -127,6 +127,16 @@ int surtr_upload_pieces(surtr_ctx* ctx, uint32_t n_pieces,
  * (Src/VMACH.cpp:302-310). */
 int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_off, const float* v012);
 
+/* Surtr::GenerateVoronoi(cellPointVec) (Src/Surtr.cpp:2003-2070, the voro++ call) on the device: the bounded Voronoi cells of
+ * the seeds in the unit box, one diagram per group (group g owns seeds [group_seed_off[g], group_seed_off[g+1]); one group for
+ * a plain pattern, one per first-level fragment for a refracture), installed as the context's fracture pattern exactly as
+ * surtr_upload_pattern would (cell = seed, in seed order).  Same cells, face order and coordinates as surtr_voronoi_cells
+ * (canonical cell: DESIGN.md section 5).  seeds: 3 doubles per seed. */
+int surtr_build_cells(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_seed_off, const double* seeds,
+                      uint32_t* n_faces, uint32_t* n_face_verts);
+/* The cells of the last surtr_build_cells in the layout of surtr_voronoi_cells (+ v012, 9 floats per face); NULL skips an array. */
+int surtr_download_cells(surtr_ctx* ctx, uint32_t* cell_face_off, int32_t* face_gen, uint32_t* face_vert_off, double* verts, float* v012);
+
 /* Polygon3D::Scale + Translate + ConstructFacePlane for every face, on the
  * device (Src/VMACH.cpp:506-534; per event at Src/Surtr.cpp:1891-1896). */
 int surtr_place_cells(surtr_ctx* ctx, const float scale[3], const float translate[3]);

@@ -167,6 +167,21 @@ struct PieceSet
     }
 };
 
+// Device buffers of surtr_build_cells (cells_dev.hip): seeds, per-cell slots, and the compact cell arrays.
+struct CellBuffers
+{
+    double* seeds = nullptr; uint32_t* goff = nullptr; char* slots = nullptr; uint32_t* cfo = nullptr; uint32_t* cvo = nullptr;
+    int32_t* gen = nullptr; uint32_t* fvo = nullptr; double* verts = nullptr;
+    size_t c_seeds = 0, c_goff = 0, c_slots = 0, c_cfo = 0, c_cvo = 0, c_gen = 0, c_fvo = 0, c_verts = 0;
+    uint32_t n = 0, nf = 0, nfv = 0;
+    void release()
+    {
+        void* all[] = {seeds, goff, slots, cfo, cvo, gen, fvo, verts};
+        for (void* p : all) if (p) (void)hipFree(p);
+        *this = CellBuffers();
+    }
+};
+
 // Half-size LDS topology of k_clip_pairs_half (capacities; the kernel is in surtr_hip.hip).
 #define SURTR_LVS (SURTR_LV / 2u)
 #define SURTR_LHS ((SURTR_LH * 11u / 24u) & ~7u)
@@ -201,6 +216,7 @@ struct surtr_ctx
     std::string err;
     // pieces
     uint32_t n_pieces = 0, vmax = 0, hmax = 0, cvmax = 0, chmax = 0;
+    CellBuffers cells;               // surtr_build_cells
     PieceSet mset, cset;             // the resident pieces: Mesh and Convex solids + what the pre-pass derives from them (pieces_dev.hip)
     uint32_t* d_upload_err = nullptr; uint32_t cap_outside = 0;
     float* d_world = nullptr; size_t c_world = 0;        // surtr_transform_pieces: the world matrices

@@ -1965,7 +1965,7 @@ void surtr_destroy(surtr_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->mset.release(); ctx->cset.release();
+    ctx->mset.release(); ctx->cset.release(); ctx->cells.release();
     free_dev(ctx->d_upload_err); free_dev(ctx->d_world); free_dev(ctx->sort_tmp); free_dev(ctx->d_from);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);

@@ -160,6 +160,23 @@ class Engine:
         self._ck(lib().surtr_upload_pieces(self._h, ctypes.c_uint32(len(meshes)), _p(m[0]), _p(m[1]), _p(m[2]), _p(m[3]),
                                            _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3])))
 
+    def build_cells(self, seeds, group_seed_off=None):
+        """surtr_build_cells: Voronoi cells of the seeds on the device, installed as the pattern.  Returns (n_faces, n_face_verts)."""
+        s = np.ascontiguousarray(seeds, np.float64).reshape(-1, 3)
+        go = np.array([0, s.shape[0]], np.uint32) if group_seed_off is None else np.ascontiguousarray(group_seed_off, np.uint32)
+        nf, nfv = ctypes.c_uint32(), ctypes.c_uint32()
+        self._ck(lib().surtr_build_cells(self._h, ctypes.c_uint32(go.shape[0] - 1), _p(go), _p(s), ctypes.byref(nf), ctypes.byref(nfv)))
+        self._cells_n = (s.shape[0], nf.value, nfv.value)
+        return nf.value, nfv.value
+
+    def download_cells(self):
+        """The cells of the last build_cells in the layout of engine.voronoi_cells (+ 'v012')."""
+        n, nf, nfv = self._cells_n
+        cfo = np.zeros(n + 1, np.uint32); gen = np.zeros(nf, np.int32); fvo = np.zeros(nf + 1, np.uint32)
+        verts = np.zeros((nfv, 3), np.float64); v012 = np.zeros((nf, 9), np.float32)
+        self._ck(lib().surtr_download_cells(self._h, _p(cfo), _p(gen), _p(fvo), _p(verts), _p(v012)))
+        return {"cell_face_off": cfo, "face_gen": gen, "face_vert_off": fvo, "verts": verts, "v012": v012}
+
     def upload_pattern(self, face_off, v012):
         fo = np.ascontiguousarray(face_off, np.uint32)
         v = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)

@@ -56,15 +56,22 @@ def box_solid(extent, center, factor=2.0):
     return {"pos": pos.astype(np.float32), "off": np.arange(0, 25, 3, dtype=np.uint32), "nbr": nb.reshape(-1)}
 
 
-def make_scene(verts, tris, n_cells, seeds=None):
+def make_scene(verts, tris, n_cells, seeds=None, eng=None):
+    """eng: an Engine -> the Voronoi cells are built on the device (surtr_build_cells, which also leaves them installed as
+    that engine's pattern); None -> the host builder (CPU tier, no GPU needed).  Same cells either way."""
     mesh = engine.neighbors_from_mesh(verts, tris)
     lo, hi = verts.min(0), verts.max(0)
     extent = (hi - lo).astype(np.float32)
     center = ((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32)
     if seeds is None:
         seeds = uniform_seeds(n_cells)
-    cells = engine.voronoi_cells(seeds)
-    face_off, v012 = engine.pattern_from_cells(cells)
+    if eng is not None:
+        eng.build_cells(seeds)
+        cells = eng.download_cells()
+        face_off, v012 = cells["cell_face_off"], cells["v012"]
+    else:
+        cells = engine.voronoi_cells(seeds)
+        face_off, v012 = engine.pattern_from_cells(cells)
     return {"mesh": mesh, "convex": box_solid(extent, center), "tris": tris, "seeds": seeds, "cells": cells,
             "face_off": face_off, "v012": v012, "scale": extent, "translate": center, "n_cells": n_cells}
 
@@ -79,9 +86,9 @@ def blob_scene(n_cells=64):
     return make_scene(v, t, n_cells)
 
 
-def torus_scene(n_cells=4096):
+def torus_scene(n_cells=4096, eng=None):
     v, t = meshgen.bumpy_torus()
-    return make_scene(v, t, n_cells)
+    return make_scene(v, t, n_cells, eng=eng)
 
 
 def fragments_as_pieces(frags):

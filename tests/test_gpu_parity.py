@@ -428,3 +428,33 @@ def test_cpp_api_surface(gpu_engine, oracle):
         same(solid(cc["by_polygon"]), solid(cc["by_planes"]))
         same(solid(cc["by_polygon"]), oracle.clip(solid(cc["box"]), np.array(cc["planes"], np.float32).reshape(-1, 4)))
         assert solid(cc["by_polygon"])["pos"].shape[0] >= 4
+
+
+# ---- Voronoi cells on the device (row A2) -------------------------------------------------------------------------------
+import test_build_cells as _bc
+
+
+@pytest.mark.parametrize("n,groups", [(8, 1), (64, 1), (1024, 1), (4096, 1), (32, 234)])
+def test_build_cells_gpu(gpu_engine, n, groups):
+    _bc.check_cells(gpu_engine, n, groups)
+
+
+def test_build_cells_time_and_event(gpu_engine, torus_run):
+    """4 096 cells in a few milliseconds (the host builder takes seconds), and the cfg4 event on them gives the golden digests."""
+    import time
+    sc, c0, got0, ref = torus_run
+    eng = gpu_engine.Engine(0)
+    eng.build_cells(sc["seeds"])
+    t0 = time.perf_counter()
+    for _ in range(3):
+        eng.build_cells(sc["seeds"])
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print("surtr_build_cells, 4096 cells: %.2f ms per call (host wall, incl. the size read-back)" % ms)
+    assert ms < 50.0
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.place_cells(sc["scale"], sc["translate"])
+    eng.fracture_event(0, 4096, flags=3)
+    got = eng.download()
+    eng.close()
+    for k in TOPO:
+        assert np.array_equal(got[k], got0[k]), k
