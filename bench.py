@@ -8,10 +8,11 @@ Mesh against every cell + island split (A7, A8, A11), refit (A12), face extracti
 RCCL's stream so that it runs beside the kernels of the next event (two blob buffers); the timed region ends
 with every gather complete.
 
-Scaling: the path partitions into independent (cell, piece) units, so by default every rank gets a FIXED
-share -- one 4096-cell pattern of its own (seed 46354 + rank; rank 0 is exactly BASELINE configs[3]) -- and
-the job grows with N ("weak").  `--scaling strong` shards the ONE 4096-cell event of configs[3] in contiguous
-cell blocks instead; at N > 1 the default run also times that mode and reports it as `strong_sharded`.
+Scaling: BASELINE's metric is the ONE 4096-cell event of configs[3] at 1 / 2 / 4 / 8 GPUs, so the headline at N > 1
+is that event with its cells sharded over the ranks in contiguous blocks ("strong": total work fixed; no data-path
+collective but the final all-gather of fragment blobs).  The path also partitions into independent (cell, piece)
+units; the same run times the weak-scaled job too -- every rank one 4096-cell pattern of its own (seed 46354 + rank)
+-- and reports it under the extra key `weak_scaled` (`--scaling weak` makes that the headline instead).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -30,6 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_build_id():
+    """Hash of the sources of the clip kernels: ties profiles/traffic.json to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("surtr_hip.hip", "clip_core.h", "surtr_ctx.h"):
+        h.update(open(os.path.join(ROOT, "surtr_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(sc, counts, n_faces):
@@ -56,7 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, all-gather) with one rank")
     args = ap.parse_args()
     # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner under
@@ -82,10 +92,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    if not os.path.exists(os.path.join(ROOT, "surtr_amd", "libsurtr_hip.so")):
-        import __graft_entry__
+    # build-if-missing: rank 0 decides for everybody (a per-rank check would let a late rank skip the barrier)
+    need = torch.tensor([0 if os.path.exists(os.path.join(ROOT, "surtr_amd", "libsurtr_hip.so")) else 1], dtype=torch.int32, device=dev)
+    if multi:
+        dist.broadcast(need, src=0)
+    if int(need.item()):
         if rank == 0:
-            __graft_entry__.build()
+            import __graft_entry__
+            __graft_entry__.build()        # writes a temporary file and renames it: no rank can load a half-written library
         if multi:
             dist.barrier()
     from surtr_amd import engine, scenes, multigpu
@@ -95,16 +109,21 @@ def main():
 
     def setup(mode):
         """Engine + inputs of this rank for one scaling mode; returns the step closure and what it gathers into."""
-        if mode == "weak" and rank > 0:
-            sc = scenes.make_scene(base["mesh"]["pos"], base["tris"], args.cells, seeds=scenes.uniform_seeds(args.cells, scenes.SEED + rank))
-        else:
-            sc = dict(base)
         eng = engine.Engine(local_rank)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
+        sc = dict(base)
+        # the Voronoi pattern is built on the device (surtr_build_cells) and stays there as this engine's pattern
+        seeds = scenes.uniform_seeds(args.cells, scenes.SEED + (rank if mode == "weak" else 0))
+        t0 = time.perf_counter()
+        eng.build_cells(seeds)
+        setup_ms["build_cells_ms"] = (time.perf_counter() - t0) * 1e3
+        cells = eng.download_cells()
+        sc["seeds"], sc["face_off"], sc["v012"] = seeds, cells["cell_face_off"], cells["v012"]
         # the piece's Convex is the reference's ACH (PrepareFracture steps 1-6), built once at set-up
         sc["convex"], _ = scenes.ach_convex(eng, sc["mesh"]["pos"])
         eng.upload_pieces([sc["mesh"]], [sc["convex"]])
-        eng.upload_pattern(sc["face_off"], sc["v012"])
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])       # second call: steady state of the piece pool
+        setup_ms["upload_ms"], setup_ms["upload_allocs"] = eng.upload_stats()
         cb, ce = (0, sc["n_cells"]) if mode == "weak" else engine.cell_block(rank, world, sc["n_cells"])
         # sizing pass: blob capacity for the timed loop (sizes are identical every step: same inputs)
         eng.place_cells(sc["scale"], sc["translate"])
@@ -142,6 +161,7 @@ def main():
         return sc, eng, step, last, cap, (cb, ce)
 
     pending = [None, None]
+    setup_ms = {}
 
     def fence():
         for k in range(2):
@@ -193,16 +213,18 @@ def main():
             all_ms.setdefault(k, []).append(v)
     eng.set_profiling(False)
 
-    strong_extra = None
-    if multi and args.scaling == "weak":
-        # the same run also times BASELINE configs[3] as ONE event sharded over the ranks (strong scaling)
+    other_extra = None
+    if multi:
+        # the same run also times the other scaling mode (extra key, never the headline)
+        other = "weak" if args.scaling == "strong" else "strong"
         eng.close()
-        sc2, eng2, step2, last2, cap2, _ = setup("strong")
+        sc2, eng2, step2, last2, cap2, _ = setup(other)
         k2 = max(3, min(args.steps, 10))
         dt2 = timed(step2, 2, k2)
         host2 = last2()[1].cpu().numpy()
         nf2 = sum(engine.unpack_blob(host2[r * cap2:(r + 1) * cap2])[0].n_frag for r in range(world))
-        strong_extra = {"ms_per_event": dt2 / k2 * 1e3, "fragments": nf2, "fragments_per_s": nf2 / (dt2 / k2), "steps": k2}
+        other_extra = {"scaling": other, "ms_per_step": dt2 / k2 * 1e3, "fragments": nf2, "fragments_per_s": nf2 / (dt2 / k2), "steps": k2,
+                       "cells": args.cells * (world if other == "weak" else 1)}
         eng2.close()
         eng = engine.Engine(local_rank)       # (closed below)
 
@@ -215,13 +237,19 @@ def main():
         ab = algorithmic_bytes(sc_rank, counts0, n_faces_rank)
         clip_avg_ms = float(np.mean(clip_ms))
         achieved = ab["clip_kernel"] / (clip_avg_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic of the kernel from the rocprofv3 PMC passes (scripts/pmc.sh), only while it describes THIS build:
+        # profiles/traffic.json records the hash of the kernel sources it was measured on
+        traffic, traffic_note = None, "no profiles/traffic.json"
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get("k_clip_pairs_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                rec = json.load(open(tj))
+                if rec.get("build_id") == kernel_build_id():
+                    traffic, traffic_note = rec.get("k_clip_pairs_hbm_bytes_per_launch"), "rocprofv3 PMC, build %s" % rec.get("build_id")
+                else:
+                    traffic_note = "profiles/traffic.json was measured on build %s, this is %s: not reported" % (rec.get("build_id"), kernel_build_id())
+            except Exception as ex:
+                traffic_note = "unreadable: %r" % (ex,)
         out = {
             "metric": "fragments/sec", "value": value, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
@@ -230,16 +258,17 @@ def main():
                                    "1 piece (mesh + its ACH convex), refit + triangulation on" % sc["n_cells"],
                        "cells": sc["n_cells"] * (world if args.scaling == "weak" else 1), "fragments": total_frag,
                        "parallelism": ("%d ranks x one %d-cell event each, one all-gather" % (world, sc["n_cells"])) if args.scaling == "weak"
-                                      else "one event, cells sharded x%d, one all-gather" % world},
+                                      else ("one event, cells sharded x%d in contiguous blocks, one all-gather" % world if world > 1 else "one GPU")},
             "ms_per_fracture_event": ms_per_step,
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
             "roofline": {"kernel": "k_clip_pairs", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": ab["clip_kernel"], "event_algorithmic_bytes": ab["event"],
                          "avg_launch_ms": clip_avg_ms},
         }
-        if strong_extra is not None:
-            out["strong_sharded"] = strong_extra
+        out["setup"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in setup_ms.items()}
+        if other_extra is not None:
+            out["weak_scaled" if other_extra["scaling"] == "weak" else "strong_sharded"] = other_extra
         if world == 1 and not args.no_cpu_baseline:
             from oracle import oracle
             threads = 16          # the reference's pool: dp::thread_pool g_threadPool(16), Src/Surtr.cpp:28

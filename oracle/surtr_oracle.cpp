@@ -307,10 +307,16 @@ static void clip(Solid& S, const std::vector<Plane>& planes)
     }
 }
 
-// Poly::ExtractFaces, Src/Poly.cpp:89-126.
-static Faces extract_faces(const Solid& S)
+// Poly::ExtractFaces, Src/Poly.cpp:89-126.  `ended` (optional): the reference's `while (cur != i)` has no bound; on a
+// degenerate solid a walk can fall into a cycle of (previous, current) states that does not hold its start vertex and the
+// reference never returns.  A walk longer than the number of half-edges has repeated a state: the restatement stops there
+// and reports it (the reference gives no result to compare with); without `ended` it is the literal, unbounded loop.
+static Faces extract_faces(const Solid& S, bool* ended = nullptr)
 {
     Faces out;
+    size_t H = 0;
+    for (const auto& r : S.nb) H += r.size();
+    if (ended) *ended = true;
     std::set<std::pair<int, int>> seen;
     for (int i = 0; i < (int)S.size(); ++i)
     {
@@ -323,6 +329,7 @@ static Faces extract_faces(const Solid& S)
             int prev = i, cur = adj;
             while (cur != i)
             {
+                if (ended && loop.size() > H) { *ended = false; return Faces(); }
                 seen.insert(std::make_pair(prev, cur));
                 loop.push_back(cur);
                 int hold = cur;
@@ -1382,7 +1389,11 @@ orc_bag* orc_event(int npieces,
             while (true)
             {
                 int k = nx.fetch_add(1); if (k >= (int)frags.size()) break;
-                orc::render(vncs[k], idxs[k], frags[k]->mesh, orc::extract_faces(frags[k]->mesh), false, orc::mk(0.25f, 0.25f, 0.25f));
+                // a fragment on which ExtractFaces would never end gets its vertices and no triangles (the engine flags
+                // it in frag_status; the reference itself hangs there)
+                bool ended = true;
+                const orc::Faces fs = orc::extract_faces(frags[k]->mesh, &ended);
+                orc::render(vncs[k], idxs[k], frags[k]->mesh, fs, false, orc::mk(0.25f, 0.25f, 0.25f));
             }
         };
         if (nt == 1) rw();

@@ -18,8 +18,8 @@
 
 #include "surtr_ctx.h"
 
-#define SURTR_CELL_V 128u      // vertices of a cell while it is being cut
-#define SURTR_CELL_G 96u       // generators that cut a cell (6 walls + seeds)
+#define SURTR_CELL_V 192u      // vertices of a cell while it is being cut
+#define SURTR_CELL_G 448u      // generators that cut a cell (6 walls + seeds)
 #define SURTR_CELL_F 64u       // faces of a finished cell
 #define SURTR_CELL_FV 384u     // face vertices of a finished cell (3 per vertex)
 
@@ -45,7 +45,7 @@ struct CellLds
     int32_t gid[SURTR_CELL_G]; D3 gn[SURTR_CELL_G]; double gc[SURTR_CELL_G];
     uint8_t seen[SURTR_CELL_V][3];
     int16_t loop[SURTR_CELL_FV]; uint16_t flo[SURTR_CELL_F + 1]; int32_t fgen[SURTR_CELL_F]; uint8_t forder[SURTR_CELL_F];
-    uint32_t nv, ng, err;
+    uint32_t nv, ng, err, nfaces;
     double r2;
 };
 
@@ -118,49 +118,67 @@ __device__ void cut_cell_serial(CellLds& L, const D3 n, const double cc)
     L.nv = (uint32_t)live;
 }
 
-// Faces of the finished cell (the second half of build_cell()), on one lane, into `o`.
-__device__ void cell_faces_serial(CellLds& L, const D3 s, CellOut& o)
+// Faces of the finished cell (the second half of build_cell()): loops on one lane, generators over the lanes, output on one lane.
+__device__ void cell_loops_serial(CellLds& L)
 {
     const int nvert = (int)L.nv;
     for (int i = 0; i < nvert; ++i) for (int j = 0; j < 3; ++j) L.seen[i][j] = 0;
     int nf = 0, lo = 0;
-    for (int i = 0; i < nvert; ++i)
+    for (int i = 0; i < nvert && L.err == 0; ++i)
         for (int j = 0; j < 3; ++j)
         {
             if (L.seen[i][j]) continue;
-            if (nf >= (int)SURTR_CELL_F) { L.err = SURTR_E_CAPACITY; return; }
+            if (nf >= (int)SURTR_CELL_F || lo >= (int)SURTR_CELL_FV) { L.err = SURTR_E_CAPACITY; break; }
             const int start = lo;
             int prev = i, cur = L.ring[i][j], len = 1;
             L.seen[i][j] = 1;
-            if (lo >= (int)SURTR_CELL_FV) { L.err = SURTR_E_CAPACITY; return; }
             L.loop[lo++] = (int16_t)i;
             while (cur != i && len <= nvert)
             {
-                if (lo >= (int)SURTR_CELL_FV) { L.err = SURTR_E_CAPACITY; return; }
+                if (lo >= (int)SURTR_CELL_FV) { L.err = SURTR_E_CAPACITY; break; }
                 L.loop[lo++] = (int16_t)cur; ++len;
                 const int nx = ring_prev3(L.ring[cur], prev);
                 for (int q = 0; q < 3; ++q) if (L.ring[cur][q] == nx) L.seen[cur][q] = 1;
                 prev = cur; cur = nx;
             }
-            // generator = the plane all loop vertices lie on
-            int best = -1; double bestErr = 1e300;
-            for (uint32_t g = 0; g < L.ng; ++g)
-            {
-                const D3 gn = L.gn[g];
-                const double nl = sqrt(gn.x * gn.x + gn.y * gn.y + gn.z * gn.z);
-                double worst = 0;
-                for (int t = start; t < lo; ++t)
-                {
-                    const D3 pv = L.p[L.loop[t]];
-                    const double e = fabs(gn.x * pv.x + gn.y * pv.y + gn.z * pv.z - L.gc[g]) / nl;
-                    worst = e > worst ? e : worst;
-                }
-                if (worst < bestErr) { bestErr = worst; best = L.gid[g]; }
-            }
-            L.flo[nf] = (uint16_t)start; L.fgen[nf] = best;
+            L.flo[nf] = (uint16_t)start;
             ++nf;
         }
     L.flo[nf] = (uint16_t)lo;
+    L.nfaces = (uint32_t)nf;
+}
+
+// generator of face f = the plane all its loop vertices lie on: the FIRST generator (in cutting order) with the smallest
+// worst distance.  Lanes take generators lane, lane + 64, ...; the reduction keeps the smaller error, then the earlier one.
+__device__ void cell_face_generator(CellLds& L, uint32_t f)
+{
+    const int a0 = L.flo[f], a1 = L.flo[f + 1];
+    double bestErr = 1e300; uint32_t bestG = 0xFFFFFFFFu;
+    for (uint32_t g = lane_id(); g < L.ng; g += SURTR_LANES)
+    {
+        const D3 gn = L.gn[g];
+        const double nl = sqrt(gn.x * gn.x + gn.y * gn.y + gn.z * gn.z);
+        double worst = 0;
+        for (int t = a0; t < a1; ++t)
+        {
+            const D3 pv = L.p[L.loop[t]];
+            const double e = fabs(gn.x * pv.x + gn.y * pv.y + gn.z * pv.z - L.gc[g]) / nl;
+            worst = e > worst ? e : worst;
+        }
+        if (worst < bestErr) { bestErr = worst; bestG = g; }
+    }
+    for (int d = SURTR_LANES / 2; d >= 1; d >>= 1)
+    {
+        const double oe = __shfl_down(bestErr, d, SURTR_LANES);
+        const uint32_t og = (uint32_t)__shfl_down((int)bestG, d, SURTR_LANES);
+        if (og != 0xFFFFFFFFu && (bestG == 0xFFFFFFFFu || oe < bestErr || (oe == bestErr && og < bestG))) { bestErr = oe; bestG = og; }
+    }
+    if (lane_id() == 0) L.fgen[f] = bestG == 0xFFFFFFFFu ? -1 : L.gid[bestG];
+}
+
+__device__ void cell_output_serial(CellLds& L, const D3 s, CellOut& o)
+{
+    const int nf = (int)L.nfaces;
     // stable order by generator id (insertion sort of the face numbers)
     for (int f = 0; f < nf; ++f)
     {
@@ -168,7 +186,7 @@ __device__ void cell_faces_serial(CellLds& L, const D3 s, CellOut& o)
         while (at > 0 && L.fgen[L.forder[at - 1]] > L.fgen[f]) { L.forder[at] = L.forder[at - 1]; --at; }
         L.forder[at] = (uint8_t)f;
     }
-    o.nf = (uint32_t)nf; o.nfv = (uint32_t)lo;
+    o.nf = (uint32_t)nf; o.nfv = (uint32_t)L.flo[nf];
     uint32_t w = 0;
     for (int k = 0; k < nf; ++k)
     {
@@ -271,11 +289,15 @@ __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, u
         }
     }
     __syncthreads();
+    if (lane == 0) { L.nfaces = 0; if (L.err == 0) cell_loops_serial(L); }
+    __syncthreads();
+    if (L.err == 0) for (uint32_t f = 0; f < L.nfaces; ++f) cell_face_generator(L, f);
+    __syncthreads();
     if (lane == 0)
     {
         CellOut& o = outv[cell];
         o.nf = 0; o.nfv = 0;
-        if (L.err == 0) cell_faces_serial(L, s, o);
+        if (L.err == 0) cell_output_serial(L, s, o);
         o.err = L.err;
     }
 }

@@ -468,6 +468,7 @@ int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_out
         if (rc) return rc;
     }
     set_piece_stats(ctx, n, vo[0].data(), ho[0].data(), vo[1].data(), ho[1].data());
+    ctx->have_event = true;       // the event's fragments are still in the arena: they can be downloaded after this call
     return finish_upload(ctx, n, false);
 }
 

@@ -433,6 +433,13 @@ def cell_block(rank, world, n_cells):
     return (rank * n_cells) // world, ((rank + 1) * n_cells) // world
 
 
+def pair_block(rank, world, n_pairs):
+    """Contiguous block of a (fragment-major) pair list for a rank: [floor(r*P/G), floor((r+1)*P/G)) -- the sharding of a
+    recursive refracture (BASELINE configs[4]): results concatenated in rank order are in list
+    order, i.e. the order in which the reference's per-compound fan-outs would return them (Src/Surtr.cpp:2129-2146)."""
+    return (rank * n_pairs) // world, ((rank + 1) * n_pairs) // world
+
+
 def hull_normals(points, limit):
     """VMACH::ConvexHull(points, limit) face normals (host helper)."""
     p = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
