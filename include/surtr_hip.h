@@ -236,6 +236,11 @@ int surtr_upload_stats(surtr_ctx* ctx, float* ms, uint32_t* n_alloc);
  * SURTR_E_TOPOLOGY where the reference throws. */
 int surtr_neighbors_from_mesh(uint32_t nv, uint32_t n_tris, const int32_t* tris, uint32_t* nbr_off, int32_t* nbr);
 
+/* The same on the device (directed-edge hash table + one fan walk per vertex): identical rings.  kernel_ms (may be NULL)
+ * returns the time of the kernels, copies excluded. */
+int surtr_neighbors_from_mesh_dev(surtr_ctx* ctx, uint32_t nv, uint32_t n_tris, const int32_t* tris, uint32_t* nbr_off, int32_t* nbr,
+                                  float* kernel_ms);
+
 /* Canonical bounded Voronoi cells of n seeds in the unit box (replaces the
  * voro++ call of Src/Surtr.cpp:2003-2070; see DESIGN.md for the face order).
  * Count-then-fill: pass NULL arrays to get n_faces / n_face_verts. */

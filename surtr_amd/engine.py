@@ -177,6 +177,17 @@ class Engine:
         self._ck(lib().surtr_download_cells(self._h, _p(cfo), _p(gen), _p(fvo), _p(verts), _p(v012)))
         return {"cell_face_off": cfo, "face_gen": gen, "face_vert_off": fvo, "verts": verts, "v012": v012}
 
+    def neighbors_from_mesh(self, pos, tris):
+        """Poly::ExtractNeighborFromMesh on the device (surtr_neighbors_from_mesh_dev) -> (solid, kernel milliseconds)."""
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        tris = np.ascontiguousarray(tris, np.int32).reshape(-1, 3)
+        off = np.zeros(pos.shape[0] + 1, np.uint32)
+        nbr = np.zeros(3 * tris.shape[0] + 4, np.int32)
+        ms = ctypes.c_float()
+        self._ck(lib().surtr_neighbors_from_mesh_dev(self._h, ctypes.c_uint32(pos.shape[0]), ctypes.c_uint32(tris.shape[0]), _p(tris), _p(off), _p(nbr),
+                                                     ctypes.byref(ms)))
+        return {"pos": pos, "off": off, "nbr": nbr[:off[-1]].copy()}, float(ms.value)
+
     def upload_pattern(self, face_off, v012):
         fo = np.ascontiguousarray(face_off, np.uint32)
         v = np.ascontiguousarray(v012, np.float32).reshape(-1, 9)

@@ -34,6 +34,7 @@ template <class T> static inline T __shfl_down(T v, int, int) { return v; }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
 typedef int hipError_t;
 typedef void* hipStream_t;

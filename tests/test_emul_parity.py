@@ -367,3 +367,41 @@ def test_fragment_with_a_face_loop_through_one_vertex_twice(emul_engine, oracle)
     ref = oracle.event([mesh], [conv], fo, d["planes"], refit=True, render=True, threads=2)
     assert c.status == 0
     assert_event_equal(got, ref)
+
+
+def check_nonterminating_faces_fragment(E, oracle):
+    """Seed 27182, case 264 of scripts/fuzz_refracture_gpu.py: one fragment (125 vertices, two rings with a doubled
+    neighbour) on which the reference's ExtractFaces never ends (Src/Poly.cpp:100-118).  It is refused alone -- no
+    triangles, SURTR_E_TOPOLOGY in frag_status, counts.n_failed = 1 -- and the event is SURTR_OK with every other fragment
+    equal to the oracle's (whose restatement stops such a walk after H steps)."""
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "nonterminating_faces_fragment.npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    fo = d["fo"].astype(np.uint32)
+    eng = E.Engine(0)
+    try:
+        eng.upload_pieces([mesh], [conv]); eng.upload_planes(fo, d["planes"])
+        c = eng.fracture_event(0, len(fo) - 1, flags=3)
+        got = eng.download()
+    finally:
+        eng.close()
+    ref = oracle.event([mesh], [conv], fo, d["planes"], refit=True, render=True, threads=2)
+    assert c.status == 0 and c.n_failed == 1 and c.n_frag >= 4
+    bad = np.nonzero(got["frag_status"])[0]
+    assert bad.shape[0] == 1 and got["frag_status"][bad[0]] == E.E_TOPOLOGY
+    assert got["idx_off"][bad[0]] == got["idx_off"][bad[0] + 1]                      # no triangles for that one
+    assert got["mesh_vert_off"][bad[0] + 1] - got["mesh_vert_off"][bad[0]] == 125
+    assert_event_equal(got, ref)
+    # the single-solid operators refuse that solid by itself
+    from helpers import fragment
+    eng = E.Engine(0)
+    try:
+        with pytest.raises(E.SurtrError) as e:
+            eng.extract_faces(fragment(got, int(bad[0])))
+        assert e.value.code == E.E_TOPOLOGY
+    finally:
+        eng.close()
+
+
+def test_nonterminating_faces_fragment_is_isolated(emul_engine, oracle):
+    check_nonterminating_faces_fragment(emul_engine, oracle)

@@ -458,3 +458,17 @@ def test_build_cells_time_and_event(gpu_engine, torus_run):
     eng.close()
     for k in TOPO:
         assert np.array_equal(got[k], got0[k]), k
+
+
+def test_one_bad_fragment_does_not_fail_the_event(gpu_engine, oracle):
+    import test_emul_parity as _ep
+    _ep.check_nonterminating_faces_fragment(gpu_engine, oracle)
+
+
+def test_refracture_fuzz_case_264_whole(gpu_engine, oracle):
+    """The whole event the fragment comes from (200 first-level cells of a 235 x 196 torus, 8 cells per piece): SURTR_OK,
+    one flagged fragment, everything else bit-equal."""
+    from test_refracture import _refracture
+    c, got, ref, npieces = _refracture(gpu_engine, oracle, 200, 8, 235, 196)
+    assert c.status == 0 and c.n_failed == 1 and int((got["frag_status"] != 0).sum()) == 1
+    assert_event_equal(got, ref)
