@@ -37,12 +37,6 @@ Poly::Polyhedron rebuild(const float* pos, const uint32_t* off, const int32_t* n
 
 namespace {
 int g_default_device = 0;
-std::vector<Plane> planes_of(const std::vector<float>& pl)
-{
-    std::vector<Plane> out(pl.size() / 4);
-    for (size_t i = 0; i < out.size(); ++i) out[i] = Plane(pl[4 * i], pl[4 * i + 1], pl[4 * i + 2], pl[4 * i + 3]);
-    return out;
-}
 std::vector<float> flat_points(const std::vector<Vector3>& v)
 {
     std::vector<float> pts; pts.reserve(3 * v.size());

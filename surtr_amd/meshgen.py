@@ -69,6 +69,30 @@ def blob(level=4, scale=1.0):
     return _outward(p.astype(np.float32), f)
 
 
+def urchin(level=4, scale=1.0, spikes=14, length=1.6, width=0.16):
+    """Closed genus-0 mesh with deep lobes for the island / non-convex ear-clipping paths of cfg2/cfg3 (the bunny's ears in
+    the large): an icosphere with `spikes` long thin spikes along fixed directions, bent sideways so that the surface is
+    not star-shaped.  A Voronoi cell between two spikes holds a piece of each: several islands per cell."""
+    v, f = icosphere(level)
+    # spike axes: a fixed spherical Fibonacci set (deterministic, no RNG)
+    k = np.arange(spikes, dtype=np.float64) + 0.5
+    phi = np.arccos(1.0 - 2.0 * k / spikes)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * k
+    axes = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], 1)
+    cosang = np.clip(v @ axes.T, -1.0, 1.0)
+    ang = np.arccos(cosang)
+    bump = np.exp(-(ang / width) ** 2)                        # one narrow bump per axis
+    r = 0.6 + length * bump.max(1)
+    p = v * r[:, None]
+    # bend every spike sideways in proportion to the square of the height above the core (overhangs: not star-shaped)
+    which = bump.argmax(1)
+    side = np.cross(axes[which], np.roll(axes, 1, axis=0)[which])
+    side /= np.maximum(np.linalg.norm(side, axis=1, keepdims=True), 1e-12)
+    h = np.maximum(r - 0.6, 0.0)
+    p = p + side * (0.35 * h * h)[:, None]
+    return _outward((p * scale).astype(np.float32), f)
+
+
 def bumpy_torus(nu=250, nv=200, R=1.0, r0=0.35):
     """cfg4: closed bumpy torus grid nu x nv -> nu*nv vertices,
     2*nu*nv triangles, valence 6 everywhere.  250 x 200 = 50 000 v / 100 000 tri."""

@@ -3,7 +3,8 @@
 The reference ships no fixtures and cannot be built here (see oracle header), so these vectors are the
 oracle's outputs -- itself pinned by tests/test_oracle_kat.py -- on the BASELINE.json configurations:
   cube8.npz        cfg1, complete inputs (seeds, planes) and complete outputs
-  digests.json     cfg2 / cfg3 / cfg4: counts + sha256 of every output array
+  digests.json     cfg2 / cfg3 / cfg4: counts + sha256 of every output array; urchin64 / urchin1024: the deep-lobed mesh of
+                   meshgen.urchin (cells with several islands, non-convex faces) at the cell counts of cfg2 / cfg3
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import hashlib
@@ -47,7 +48,8 @@ def main():
                         mesh_pos=sc["mesh"]["pos"], mesh_off=sc["mesh"]["off"], mesh_nbr=sc["mesh"]["nbr"],
                         **{"out_" + k: ev[k] for k in KEYS})
     out = {}
-    for name, sc in (("blob64", scenes.blob_scene(64)), ("blob1024", scenes.blob_scene(1024)), ("torus4096", scenes.torus_scene(4096))):
+    for name, sc in (("blob64", scenes.blob_scene(64)), ("blob1024", scenes.blob_scene(1024)), ("torus4096", scenes.torus_scene(4096)),
+                     ("urchin64", scenes.urchin_scene(64)), ("urchin1024", scenes.urchin_scene(1024))):
         _, ev = run(sc)
         out[name] = digest(ev)
         print(name, out[name]["n_frag"], out[name]["mesh_verts"], out[name]["n_idx"])

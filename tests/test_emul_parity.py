@@ -405,3 +405,10 @@ def check_nonterminating_faces_fragment(E, oracle):
 
 def test_nonterminating_faces_fragment_is_isolated(emul_engine, oracle):
     check_nonterminating_faces_fragment(emul_engine, oracle)
+
+
+def test_deep_lobed_mesh_emulated(emul_engine, oracle):
+    """meshgen.urchin x 64 cells (the GPU tier also runs 1 024): several islands per cell in a quarter of the cells."""
+    c, got, ref = run_event(emul_engine, oracle, scenes.urchin_scene(64))
+    assert c.status == 0 and int(got["frag_ids"][:, 2].max()) >= 1
+    assert_event_equal(got, ref)

@@ -472,3 +472,54 @@ def test_refracture_fuzz_case_264_whole(gpu_engine, oracle):
     c, got, ref, npieces = _refracture(gpu_engine, oracle, 200, 8, 235, 196)
     assert c.status == 0 and c.n_failed == 1 and int((got["frag_status"] != 0).sum()) == 1
     assert_event_equal(got, ref)
+
+
+@pytest.mark.parametrize("name,n", [("urchin64", 64), ("urchin1024", 1024)])
+def test_deep_lobed_mesh_islands(gpu_engine, oracle, name, n):
+    """cfg2 / cfg3 cell counts on the deep-lobed mesh (meshgen.urchin): at least a tenth of the non-empty cells hold two or
+    more islands, faces are far from convex; full equality with the oracle and the committed digests."""
+    c, got, ref = run_event(gpu_engine, oracle, scenes.urchin_scene(n), 3, threads=8)
+    assert c.status == 0 and c.n_failed == 0
+    assert_event_equal(got, ref)
+    ids = got["frag_ids"]
+    cells = np.unique(ids[:, 0])
+    multi = sum(1 for cc in cells if int((ids[:, 0] == cc).sum()) > 1)
+    assert multi >= 0.1 * cells.shape[0], (multi, cells.shape[0])
+    want = json.load(open(os.path.join(HERE, "digests.json")))[name]
+    assert c.n_frag == want["n_frag"] and c.mesh_verts == want["mesh_verts"] and c.n_idx == want["n_idx"]
+    for k in TOPO:
+        assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == want[k], k
+
+
+def test_device_rings_gpu(gpu_engine):
+    """Row f3: ExtractNeighborFromMesh on the device, identical rings; the 100 000-triangle torus in a few milliseconds."""
+    import test_host_helpers as _hh
+    _hh.check_device_rings(gpu_engine)
+    v, t = meshgen.bumpy_torus()
+    want = gpu_engine.neighbors_from_mesh(v, t)
+    eng = gpu_engine.Engine(0)
+    eng.neighbors_from_mesh(v, t)
+    got, ms = eng.neighbors_from_mesh(v, t)
+    eng.close()
+    assert np.array_equal(got["off"], want["off"]) and np.array_equal(got["nbr"], want["nbr"])
+    print("surtr_neighbors_from_mesh_dev, 100 000 triangles: %.3f ms of kernels" % ms)
+    assert 0 < ms < 5.0
+
+
+def test_cpp_rccl_harness_single_rank(oracle):
+    """The C++ exchange step (surtr_rccl.cpp: ncclAllGather of sizes, then of the packed blobs) on a 1-rank communicator:
+    what one GPU can rehearse; the N-rank run forks one process per GPU (surtr_harness_mgpu --ranks N)."""
+    import json as js
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "surtr_amd", "host")])
+    exe = os.path.join(root, "surtr_amd", "host", "surtr_harness_mgpu")
+    out = js.loads(subprocess.check_output([exe, "--ranks", "1", "--cells", "256", "--nu", "100", "--nv", "60", "--steps", "2"], timeout=300).decode().strip().splitlines()[-1])
+    sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+    v = sc["mesh"]["pos"]; lo, hi = v.min(0), v.max(0)
+    nrm = oracle.hull_normals(v, 20)
+    pl = oracle.kdop_planes(v, nrm, ach=True, max_axis_scale=float(max(float(hi[a]) - float(lo[a]) for a in range(3))), gap_inv=2000.0)
+    ach = oracle.clip(scenes.box_solid(sc["scale"], sc["translate"]), pl)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [ach], sc["face_off"], planes, threads=8)
+    assert out["ranks"] == 1 and out["fragments"] == ref["frag_ids"].shape[0] and out["per_rank"] == [ref["frag_ids"].shape[0]]
