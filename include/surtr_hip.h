@@ -295,6 +295,15 @@ int surtr_regroup(uint32_t n_pieces, uint32_t n_outside, const int32_t* piece_ce
                   int partial, uint32_t n_sphere, const float* sphere_points, const float origin[3], float radius,
                   uint32_t* n_compounds, uint32_t* compound_off, int32_t* compound_piece);
 
+/* The same regrouping as a device step on the last event (regroup_dev.hip): the Convex solids stay in HBM; faces, planes, the
+ * ConvexOutOfSphere test, candidate face pairs (radix sort by |d|), the overlap tests and the label propagation over pieces
+ * run in kernels; only per-piece flags and labels come back.  Pieces are numbered as for surtr_regroup: the resident pieces
+ * the event skipped (its `outside` mask, ascending), then the event's fragments in output order.  Call it BEFORE
+ * surtr_event_refit (the reference regroups on the un-refitted Convex solids).  compound_off needs *n_pieces + 2 entries,
+ * compound_piece *n_pieces (call with both NULL to get n_pieces). */
+int surtr_event_regroup(surtr_ctx* ctx, int partial, uint32_t n_sphere, const float* sphere_points, const float origin[3], float radius,
+                        uint32_t* n_pieces, uint32_t* n_compounds, uint32_t* compound_off, int32_t* compound_piece);
+
 /* Runs m_refittingTask (and the output scan) on the fragments of the last event: the reference regroups on the
  * un-refitted Convex solids and refits afterwards (Src/Surtr.cpp:1921-1939). */
 int surtr_event_refit(surtr_ctx* ctx);

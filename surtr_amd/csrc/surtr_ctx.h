@@ -244,6 +244,7 @@ struct surtr_ctx
     uint2* d_scanblk = nullptr; uint32_t cap_scanblk = 0;
     surtr_counts* d_counts = nullptr;
     uint8_t* d_outside = nullptr;
+    std::vector<uint8_t> last_outside;       // the `outside` mask of the last event (empty: none), for surtr_event_regroup
     uint2* d_pair_list = nullptr; uint32_t cap_pair_list = 0;
     float color[3] = {0.25f, 0.25f, 0.25f};      // VertexNormalColor::Color written by k_pack (Inc/Poly.h:68 default)
     surtr_counts last{}; bool last_current = false;     // `last` holds the counts of the event in the arena

@@ -2262,6 +2262,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
     HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
     const uint8_t* d_out = nullptr;
+    ctx->last_outside.clear();
+    if (outside) ctx->last_outside.assign(outside, outside + ctx->n_pieces);
     if (outside)
     {
         HIPCHK(hipMemcpyAsync(ctx->d_outside, outside, ctx->n_pieces, hipMemcpyHostToDevice, st));

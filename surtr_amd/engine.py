@@ -230,6 +230,17 @@ class Engine:
         self._ck(lib().surtr_fracture_pairs_async(self._h, ctypes.c_uint32(pc.shape[0]), _p(pc), _p(pp), ctypes.c_uint32(flags)))
         return self.event_counts()
 
+    def event_regroup(self, partial=False, sphere_points=None, origin=(0, 0, 0), radius=1.0):
+        """surtr_event_regroup: bind sets + MergeOutOfImpact + HandleConvexIsland of the last event, on the device."""
+        sp = np.zeros((0, 3), np.float32) if sphere_points is None else np.ascontiguousarray(sphere_points, np.float32).reshape(-1, 3)
+        org = np.ascontiguousarray(origin, np.float32)
+        n, nc = ctypes.c_uint32(), ctypes.c_uint32()
+        args = [self._h, ctypes.c_int(int(partial)), ctypes.c_uint32(sp.shape[0]), _p(sp), _p(org), ctypes.c_float(radius)]
+        self._ck(lib().surtr_event_regroup(*args, ctypes.byref(n), ctypes.byref(nc), None, None))
+        co = np.zeros(n.value + 2, np.uint32); cp = np.zeros(max(n.value, 1), np.int32)
+        self._ck(lib().surtr_event_regroup(*args, ctypes.byref(n), ctypes.byref(nc), _p(co), _p(cp)))
+        return co[:nc.value + 1].copy(), cp[:co[nc.value]].copy()
+
     def event_refit(self):
         self._ck(lib().surtr_event_refit(self._h))
 

@@ -46,6 +46,8 @@ def check_regroup_and_refit_order(emul_engine, oracle, n_first=24, n_second=5, t
     co, cp = emul_engine.regroup(conv, ev["frag_ids"][:, 0])
     ro, rp = oracle.regroup(conv, ev["frag_ids"][:, 0])
     assert np.array_equal(co, ro) and np.array_equal(cp, rp)
+    do, dp = eng.event_regroup()                       # the same as a device step on the resident fragments
+    assert np.array_equal(do, ro) and np.array_equal(dp, rp)
     assert co.shape[0] - 1 >= n_second + 1           # bind 0 + one compound per cell (+ splits)
     assert sorted(cp.tolist()) == list(range(c.n_frag))
     # islands of compounds were actually found somewhere (pieces of one cell that do not touch)
@@ -80,6 +82,8 @@ def check_partial_fracture_merges_out_of_impact(emul_engine, oracle, n_first=24,
     ro, rp = oracle.regroup(pieces, cell, n_outside=n_out, partial=True, sphere_points=cloud, origin=impact, radius=radius)
     assert np.array_equal(co, ro) and np.array_equal(cp, rp)
     assert np.diff(co.astype(np.int64))[0] >= n_out          # the outside compound only grows
+    do, dp = eng.event_regroup(partial=True, sphere_points=cloud, origin=impact, radius=radius)
+    assert np.array_equal(do, ro) and np.array_equal(dp, rp)
     eng.close()
 
 
