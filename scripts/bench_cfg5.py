@@ -1,26 +1,54 @@
-"""Times BASELINE configs[4] (recursive refracture: 256 first-level fragments x 32 cells each) on the GPU."""
+"""BASELINE configs[4] (recursive refracture: 256 first-level cells, every fragment re-split into 32 cells) end to end on the
+GPU, the first level's fragments never leaving HBM:
+    level 1 event -> surtr_pieces_from_event -> surtr_build_cells (one Voronoi diagram per fragment) -> placement per
+    fragment -> level 2 event over the (fragment, cell) pair list.
+Prints the wall time of the whole chain next to the two events alone."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from surtr_amd import engine as E, scenes as S, meshgen as G
 if os.environ.get('SURTR_LIB'):
     E._use_library_for_tests(os.path.abspath(os.environ['SURTR_LIB']))
-sc = S.make_scene(*G.bumpy_torus(), 256)
+N1, N2 = 256, 32
 eng = E.Engine(0)
-eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
-t0 = time.perf_counter(); c = eng.fracture_event(0, 256, flags=1); t1 = time.perf_counter()
-print("level 1: 256 cells, %d fragments, %.2f ms (first call, allocations included)" % (c.n_frag, (t1 - t0) * 1e3))
-first = eng.download()
-meshes, convexes = S.fragments_as_pieces(first)
-keep = [i for i, m in enumerate(meshes) if m["pos"].shape[0] >= 4 and np.diff(m["off"].astype(np.int64)).min() >= 3 and convexes[i]["pos"].shape[0] >= 4]
-meshes, convexes = [meshes[i] for i in keep], [convexes[i] for i in keep]
-rs = S.refracture_scene(meshes, convexes, 32)
-eng.upload_pieces(meshes, convexes); eng.upload_pattern(rs["face_off"], rs["v012"]); eng.place_cells_groups(rs["group_cell_off"], rs["scales"], rs["shifts"])
+sc = S.make_scene(*G.bumpy_torus(), N1, eng=eng)
+pat1 = (sc["face_off"], sc["v012"])
+
+
+def level1():
+    eng.upload_pattern(*pat1); eng.place_cells(sc["scale"], sc["translate"])
+    return eng.fracture_event(0, N1, flags=1)
+
+
+def between(c1):
+    """first level's fragments -> pieces, their boxes -> the second pattern and its pair list"""
+    n = eng.pieces_from_event()
+    fr = eng.download()                      # (only the boxes are needed on the host: one D2H of the level-1 blob)
+    vo = fr["mesh_vert_off"].astype(np.int64)
+    lo = np.minimum.reduceat(fr["mesh_pos"], vo[:-1]); hi = np.maximum.reduceat(fr["mesh_pos"], vo[:-1])
+    scales = (hi - lo).astype(np.float32); shifts = ((hi.astype(np.float64) + lo) / 2.0).astype(np.float32)
+    seeds = np.concatenate([S.uniform_seeds(N2, S.SEED + p) for p in range(n)])
+    eng.build_cells(seeds, np.arange(0, n * N2 + 1, N2, dtype=np.uint32))
+    go = np.arange(0, n * N2 + 1, N2, dtype=np.uint32)
+    eng.place_cells_groups(go, scales, shifts)
+    return n, np.arange(n * N2, dtype=np.uint32), np.repeat(np.arange(n, dtype=np.uint32), N2)
+
+
+eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+seed_cache = {}
+for rep in range(4):
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    t0 = time.perf_counter(); c1 = level1(); t1 = time.perf_counter()
+    n, pc, pp = between(c1); t2 = time.perf_counter()
+    c2 = eng.fracture_pairs(pc, pp, flags=3); t3 = time.perf_counter()
+    print("rep %d: level 1 %d cells -> %d fragments %.2f ms | fragments -> pieces + %d x %d cells built and placed %.2f ms | level 2 %d pairs -> %d fragments %.2f ms | chain %.2f ms" % (
+        rep, N1, c1.n_frag, (t1 - t0) * 1e3, n, N2, (t2 - t1) * 1e3, pc.shape[0], c2.n_frag, (t3 - t2) * 1e3, (t3 - t0) * 1e3), flush=True)
 eng.set_profiling(True)
 ts = []
 for _ in range(6):
-    t0 = time.perf_counter(); c = eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=3); ts.append((time.perf_counter() - t0) * 1e3)
+    t0 = time.perf_counter(); c2 = eng.fracture_pairs(pc, pp, flags=3); ts.append((time.perf_counter() - t0) * 1e3)
 kt = eng.kernel_times()
-print("level 2: %d pieces x 32 cells = %d pairs, %d fragments, %d mesh verts: %.2f ms per event; kernels %s" % (
-    len(meshes), rs["pair_cell"].shape[0], c.n_frag, c.mesh_verts, min(ts), {k: round(v, 3) for k, v in kt.items() if v >= 0}))
+print("level 2 alone: %d pairs, %d fragments, %d mesh verts: %.2f ms per event; kernels %s" % (
+    pc.shape[0], c2.n_frag, c2.mesh_verts, min(ts), {k: round(v, 3) for k, v in kt.items() if v >= 0}))
+print("upload stats of the last pieces_from_event: %.3f ms host, %d allocations" % eng.upload_stats())
 eng.close()

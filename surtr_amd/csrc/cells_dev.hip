@@ -14,6 +14,8 @@
 #ifndef SURTR_EMUL
 #include <hip/hip_runtime.h>
 #endif
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 
 #include "surtr_ctx.h"
@@ -220,7 +222,7 @@ __device__ void cell_output_serial(CellLds& L, const D3 s, CellOut& o)
 
 // cell c of group g: seeds [goff[g], goff[g+1]); one wave per cell
 __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, uint32_t n_groups, const uint32_t* __restrict__ goff,
-                                                             const double* __restrict__ seeds, CellOut* __restrict__ outv)
+                                                             const double* __restrict__ seeds, CellOut* __restrict__ outv, uint32_t* __restrict__ heads)
 {
     __shared__ CellLds L;
     const uint32_t cell = blockIdx.x, lane = threadIdx.x;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, u
         o.nf = 0; o.nfv = 0;
         if (L.err == 0) cell_output_serial(L, s, o);
         o.err = L.err;
+        heads[4 * (size_t)cell] = o.nf; heads[4 * (size_t)cell + 1] = o.nfv; heads[4 * (size_t)cell + 2] = o.err;      // one contiguous read-back
     }
 }
 
@@ -352,16 +355,16 @@ int surtr_build_cells(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_s
     HIPCHK(hipMemcpyAsync(B.seeds, seeds, (size_t)n * 24, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(B.goff, group_seed_off, ((size_t)n_groups + 1) * 4, hipMemcpyHostToDevice, st));
     CellOut* slots = (CellOut*)B.slots;
-    hipLaunchKernelGGL(k_build_cells, dim3(n), dim3(SURTR_LANES), 0, st, n, n_groups, B.goff, B.seeds, slots);
+    rc = grow(ctx, &B.heads, B.c_heads, 4 * (size_t)n);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_build_cells, dim3(n), dim3(SURTR_LANES), 0, st, n, n_groups, B.goff, B.seeds, slots, B.heads);
     HIPCHK(hipGetLastError());
     // sizes per cell -> offsets (a few bytes per cell cross the bus; the cells themselves stay in HBM)
     std::vector<uint32_t> head(4 * (size_t)n);
-#ifndef SURTR_EMUL
-    HIPCHK(hipMemcpy2DAsync(head.data(), 16, slots, sizeof(CellOut), 16, n, hipMemcpyDeviceToHost, st));
-#else
-    for (uint32_t c = 0; c < n; ++c) memcpy(&head[4 * (size_t)c], &slots[c], 16);
-#endif
+    HIPCHK(hipMemcpyAsync(head.data(), B.heads, head.size() * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<uint32_t> cfo(n + 1, 0u), cvo(n + 1, 0u);
     for (uint32_t c = 0; c < n; ++c)
     {
@@ -375,11 +378,16 @@ int surtr_build_cells(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_s
     if (rc == 0) rc = grow(ctx, &B.verts, B.c_verts, 3 * (size_t)nfv);
     if (rc) return rc;
     // the pattern buffers of the context (what surtr_upload_pattern fills)
-    free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
-    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr;
-    HIPCHK(hipMalloc((void**)&ctx->d_v012, std::max<size_t>(16, (size_t)nf * 36)));
-    HIPCHK(hipMalloc((void**)&ctx->d_planes, std::max<size_t>(16, (size_t)nf * 16)));
-    HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(n + 1) * 4));
+    if (!(ctx->d_v012 && ctx->d_planes && ctx->d_plane_off && ctx->cap_pattern_faces >= nf && ctx->cap_pattern_cells >= n))
+    {
+        free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
+        ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr; ctx->cap_pattern_faces = 0; ctx->cap_pattern_cells = 0;
+        const uint32_t capf = nf + nf / 8 + 16, capc = n + n / 8 + 16;
+        HIPCHK(hipMalloc((void**)&ctx->d_v012, (size_t)capf * 36));
+        HIPCHK(hipMalloc((void**)&ctx->d_planes, (size_t)capf * 16));
+        HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(capc + 1) * 4));
+        ctx->cap_pattern_faces = capf; ctx->cap_pattern_cells = capc;
+    }
     HIPCHK(hipMemcpyAsync(B.cfo, cfo.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(B.cvo, cvo.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->d_plane_off, cfo.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, st));
@@ -389,6 +397,9 @@ int surtr_build_cells(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_s
     ctx->h_plane_off.assign(cfo.begin(), cfo.end());
     ctx->n_cells = n; ctx->n_faces = nf; ctx->planes_ready = false; ctx->pair_order_count = 0;
     B.n = n; B.nf = nf; B.nfv = nfv;
+    if (getenv("SURTR_TIMING"))
+        fprintf(stderr, "surtr_build_cells: %u cells, kernel + size read-back %.3f ms, pack + pattern %.3f ms\n", n,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     if (n_faces) *n_faces = nf;
     if (n_face_verts) *n_face_verts = nfv;
     return SURTR_OK;

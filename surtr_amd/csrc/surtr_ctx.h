@@ -171,12 +171,12 @@ struct PieceSet
 struct CellBuffers
 {
     double* seeds = nullptr; uint32_t* goff = nullptr; char* slots = nullptr; uint32_t* cfo = nullptr; uint32_t* cvo = nullptr;
-    int32_t* gen = nullptr; uint32_t* fvo = nullptr; double* verts = nullptr;
-    size_t c_seeds = 0, c_goff = 0, c_slots = 0, c_cfo = 0, c_cvo = 0, c_gen = 0, c_fvo = 0, c_verts = 0;
+    int32_t* gen = nullptr; uint32_t* fvo = nullptr; double* verts = nullptr; uint32_t* heads = nullptr;
+    size_t c_heads = 0, c_seeds = 0, c_goff = 0, c_slots = 0, c_cfo = 0, c_cvo = 0, c_gen = 0, c_fvo = 0, c_verts = 0;
     uint32_t n = 0, nf = 0, nfv = 0;
     void release()
     {
-        void* all[] = {seeds, goff, slots, cfo, cvo, gen, fvo, verts};
+        void* all[] = {seeds, goff, slots, cfo, cvo, gen, fvo, verts, heads};
         for (void* p : all) if (p) (void)hipFree(p);
         *this = CellBuffers();
     }
@@ -225,7 +225,7 @@ struct surtr_ctx
     float upload_ms = 0.f; uint32_t upload_allocs = 0;   // surtr_upload_stats
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
-    uint32_t n_cells = 0, n_faces = 0;
+    uint32_t n_cells = 0, n_faces = 0, cap_pattern_faces = 0, cap_pattern_cells = 0;      // (capacities: set by surtr_build_cells only)
     uint32_t* d_pair_order = nullptr; uint32_t pair_order_begin = 0, pair_order_count = 0, cap_pair_order = 0;   // k_clip_convex: pairs by plane count
     bool pair_order_is_list = false;
     float* d_v012 = nullptr; float4* d_planes = nullptr; uint32_t* d_plane_off = nullptr;

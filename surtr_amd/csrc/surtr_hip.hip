@@ -2039,7 +2039,7 @@ int surtr_upload_pattern(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* face_
     for (uint32_t c = 0; c < n_cells; ++c)
         if (face_off[c + 1] < face_off[c] || face_off[c + 1] - face_off[c] > SURTR_MAXF) return SURTR_E_INVALID;
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
-    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr;
+    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr; ctx->cap_pattern_faces = 0; ctx->cap_pattern_cells = 0;
     HIPCHK(hipMalloc((void**)&ctx->d_v012, std::max<size_t>(16, (size_t)nf * 36)));
     HIPCHK(hipMalloc((void**)&ctx->d_planes, std::max<size_t>(16, (size_t)nf * 16)));
     HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(n_cells + 1) * 4));
@@ -2072,7 +2072,7 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
     for (uint32_t c = 0; c < n_cells; ++c)
         if (plane_off[c + 1] < plane_off[c] || plane_off[c + 1] - plane_off[c] > SURTR_MAXF) return SURTR_E_INVALID;
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
-    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr;
+    ctx->d_v012 = nullptr; ctx->d_planes = nullptr; ctx->d_plane_off = nullptr; ctx->cap_pattern_faces = 0; ctx->cap_pattern_cells = 0;
     HIPCHK(hipMalloc((void**)&ctx->d_planes, std::max<size_t>(16, (size_t)nf * 16)));
     HIPCHK(hipMalloc((void**)&ctx->d_plane_off, (size_t)(n_cells + 1) * 4));
     HIPCHK(hipMemcpy(ctx->d_planes, planes, (size_t)nf * 16, hipMemcpyHostToDevice));
