@@ -169,6 +169,11 @@ int surtr_fracture_pairs_async(surtr_ctx* ctx, uint32_t n_pairs, const uint32_t*
 int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* scale3,
                              const float* translate3);
 
+/* The same with group g placed over the bounding box of resident piece g's Mesh (scale = its extent, translate = its centre,
+ * Src/Surtr.cpp:1799-1803 applied per piece): the boxes are taken on the device, nothing is read back.  n_groups must equal the
+ * number of resident pieces (a recursive refracture after surtr_pieces_from_event + surtr_build_cells). */
+int surtr_place_cells_in_pieces(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off);
+
 /* Bytes of the packed device blob holding the last event's fragments. */
 size_t surtr_event_blob_bytes(const surtr_counts* counts);
 /* Packs the last event's fragments into one contiguous device buffer (for an
@@ -220,7 +225,9 @@ int surtr_event_triangulate(surtr_ctx* ctx, int is_convex);
  * (ExecuteFractureRoutine's pre-transform, Src/Surtr.cpp:1846-1851).  No host round trip. */
 int surtr_transform_pieces(surtr_ctx* ctx, uint32_t n_pieces, const float* world);
 /* The fragments of the last event become the resident pieces (recursive refracture without leaving HBM): fragment k is kept
- * when keep == NULL or keep[k] != 0; kept fragments become pieces 0, 1, ... in fragment order.  n_pieces returns their number. */
+ * when keep[k] != 0; keep == NULL keeps every fragment that is a solid (at least four vertices in Mesh and Convex; a Convex the
+ * refit clipped away yields nothing in the reference either, Src/Surtr.cpp:1466-1468).  Kept fragments become pieces 0, 1, ...
+ * in fragment order; n_pieces returns their number. */
 int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_pieces);
 /* Reads resident piece `piece` back (set 0 = Mesh, 1 = Convex): count-then-fill like surtr_clip_polyhedron.  For tests and for
  * Poly::Transform of a single host polyhedron; the event path never needs it. */

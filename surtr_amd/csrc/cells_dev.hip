@@ -47,8 +47,8 @@ struct CellLds
     int32_t gid[SURTR_CELL_G]; D3 gn[SURTR_CELL_G]; double gc[SURTR_CELL_G];
     uint8_t seen[SURTR_CELL_V][3];
     int16_t loop[SURTR_CELL_FV]; uint16_t flo[SURTR_CELL_F + 1]; int32_t fgen[SURTR_CELL_F]; uint8_t forder[SURTR_CELL_F];
-    uint32_t nv, ng, err, nfaces;
-    double r2;
+    uint32_t nv, ng, err, nfaces, flag[2], cut_lane;
+    double r2; D3 cut_n; double cut_c;
 };
 
 __device__ __forceinline__ int ring_prev3(const int16_t* r, int who)
@@ -60,39 +60,67 @@ __device__ __forceinline__ int ring_prev3(const int16_t* r, int who)
 
 __device__ __forceinline__ double plane_side(const D3 n, double cc, const D3 p) { return n.x * p.x + n.y * p.y + n.z * p.z - cc; }
 
-// cut_cell() of host_geom.cpp on one lane: keep n.x <= cc.
-__device__ void cut_cell_serial(CellLds& L, const D3 n, const double cc)
+// cut_cell() of host_geom.cpp over the lanes of the wave: keep n.x <= cc.  Same results as the sequential code: new
+// vertices are numbered in (cut vertex, ring slot) order by a prefix sum, every other step touches disjoint entries.
+// Every lane must call it (barriers inside).
+__device__ void cut_cell_wave(CellLds& L, const D3 n, const double cc)
 {
     const int n0 = (int)L.nv;
+    const uint32_t lane = lane_id();
+    if (lane == 0) { L.flag[0] = 0; L.flag[1] = 0; }
+    __syncthreads();
     bool any_out = false, any_in = false;
-    for (int i = 0; i < n0; ++i)
+    for (int i = (int)lane; i < n0; i += SURTR_LANES)
     {
-        L.s[i] = plane_side(n, cc, L.p[i]);
-        if (L.s[i] > 0) any_out = true; else any_in = true;
+        const double si = plane_side(n, cc, L.p[i]);
+        L.s[i] = si; L.out[i] = si > 0 ? 1 : 0;
+        if (si > 0) any_out = true; else any_in = true;
     }
-    if (!any_out) return;
-    if (!any_in) { L.nv = 0; return; }
-    for (int i = 0; i < n0; ++i) L.out[i] = L.s[i] > 0 ? 1 : 0;
-    int n1 = n0;
-    for (int i = 0; i < n0; ++i)
+    if (any_out) L.flag[0] = 1;
+    if (any_in) L.flag[1] = 1;
+    __syncthreads();
+    if (!L.flag[0]) return;
+    if (!L.flag[1]) { __syncthreads(); if (lane == 0) L.nv = 0; __syncthreads(); return; }
+    // crossing edges per cut vertex, numbered in (vertex, slot) order
+    uint32_t carry = 0;
+    for (int i0 = 0; i0 < n0; i0 += SURTR_LANES)
+    {
+        const int i = i0 + (int)lane;
+        uint32_t cnt = 0;
+        if (i < n0 && L.out[i])
+            for (int j = 0; j < 3; ++j) { const int k = L.ring[i][j]; if (k < n0 && !L.out[k]) ++cnt; }
+        const uint2 inc = wave_incl_scan2(make_uint2(cnt, 0u));
+        if (i < n0) L.id[i] = (int16_t)(carry + inc.x - cnt);          // first new vertex of cut vertex i (relative)
+#ifdef SURTR_EMUL
+        carry += inc.x;
+#else
+        carry += (uint32_t)__shfl((int)inc.x, SURTR_LANES - 1, SURTR_LANES);
+#endif
+    }
+    const int n1 = n0 + (int)carry;
+    if (n1 > (int)SURTR_CELL_V) { if (lane == 0) L.err = SURTR_E_CAPACITY; __syncthreads(); return; }
+    __syncthreads();
+    for (int i = (int)lane; i < n0; i += SURTR_LANES)
     {
         if (!L.out[i]) continue;
+        int fresh = n0 + L.id[i];
         for (int j = 0; j < 3; ++j)
         {
             const int k = L.ring[i][j];
             if (k >= n0 || L.out[k]) continue;
-            if (n1 >= (int)SURTR_CELL_V) { L.err = SURTR_E_CAPACITY; return; }
             const double t = L.s[k] / (L.s[k] - L.s[i]);            // from the kept end towards the cut end
             const D3 a = L.p[k], b = L.p[i];
-            const int fresh = n1++;
             L.p[fresh] = D3{a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z)};
             L.ring[fresh][0] = (int16_t)i; L.ring[fresh][1] = (int16_t)k; L.ring[fresh][2] = -1;
             for (int e = 0; e < 3; ++e) if (L.ring[k][e] == i) { L.ring[k][e] = (int16_t)fresh; break; }
             L.ring[i][j] = (int16_t)fresh;
+            ++fresh;
         }
     }
-    for (int x = 0; x < n1; ++x) { L.succ[x] = -1; L.pred[x] = -1; }
-    for (int x = n0; x < n1; ++x)
+    for (int x = (int)lane; x < n1; x += SURTR_LANES) { L.succ[x] = -1; L.pred[x] = -1; }
+    __syncthreads();
+    // cap: successor of every new vertex along the face through its cut end
+    for (int x = n0 + (int)lane; x < n1; x += SURTR_LANES)
     {
         int prev = x, cur = L.ring[x][0], guard = 0;
         while (cur < n0 && L.out[cur] && guard++ < n1)
@@ -103,21 +131,39 @@ __device__ void cut_cell_serial(CellLds& L, const D3 n, const double cc)
         L.succ[x] = (int16_t)cur;
         if (cur >= n0) L.pred[cur] = (int16_t)x;
     }
-    for (int x = n0; x < n1; ++x)
+    __syncthreads();
+    for (int x = n0 + (int)lane; x < n1; x += SURTR_LANES)
     {
         const int16_t kept = L.ring[x][1];
         L.ring[x][0] = L.pred[x]; L.ring[x][1] = L.succ[x]; L.ring[x][2] = kept;
     }
-    int live = 0;
-    for (int i = 0; i < n1; ++i) L.id[i] = (i >= n0 || !L.out[i]) ? (int16_t)live++ : (int16_t)-1;
-    for (int i = 0; i < n1; ++i)
+    __syncthreads();
+    // compaction (order preserving)
+    carry = 0;
+    for (int i0 = 0; i0 < n1; i0 += SURTR_LANES)
+    {
+        const int i = i0 + (int)lane;
+        const uint32_t keep = (i < n1 && (i >= n0 || !L.out[i])) ? 1u : 0u;
+        const uint2 inc = wave_incl_scan2(make_uint2(keep, 0u));
+        if (i < n1) L.id[i] = keep ? (int16_t)(carry + inc.x - 1u) : (int16_t)-1;
+#ifdef SURTR_EMUL
+        carry += inc.x;
+#else
+        carry += (uint32_t)__shfl((int)inc.x, SURTR_LANES - 1, SURTR_LANES);
+#endif
+    }
+    const int live = (int)carry;
+    __syncthreads();
+    for (int i = (int)lane; i < n1; i += SURTR_LANES)
     {
         if (L.id[i] < 0) continue;
         L.q[L.id[i]] = L.p[i];
         for (int e = 0; e < 3; ++e) { const int r = L.ring[i][e]; L.ring2[L.id[i]][e] = r >= 0 ? L.id[r] : (int16_t)-1; }
     }
-    for (int i = 0; i < live; ++i) { L.p[i] = L.q[i]; for (int e = 0; e < 3; ++e) L.ring[i][e] = L.ring2[i][e]; }
-    L.nv = (uint32_t)live;
+    __syncthreads();
+    for (int i = (int)lane; i < live; i += SURTR_LANES) { L.p[i] = L.q[i]; for (int e = 0; e < 3; ++e) L.ring[i][e] = L.ring2[i][e]; }
+    if (lane == 0) L.nv = (uint32_t)live;
+    __syncthreads();
 }
 
 // Faces of the finished cell (the second half of build_cell()): loops on one lane, generators over the lanes, output on one lane.
@@ -242,17 +288,19 @@ __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, u
         L.ng = 6;
     }
     __syncthreads();
-    auto radius2 = [&]() {      // (lane 0) max squared distance of a cell vertex from the seed
+    auto radius2 = [&]() {      // (all lanes) max squared distance of a cell vertex from the seed
         double r2 = 0;
-        for (uint32_t i = 0; i < L.nv; ++i)
+        for (uint32_t i = lane; i < L.nv; i += SURTR_LANES)
         {
             const double dx = L.p[i].x - s.x, dy = L.p[i].y - s.y, dz = L.p[i].z - s.z, d = dx * dx + dy * dy + dz * dz;
             r2 = d > r2 ? d : r2;
         }
-        L.r2 = r2;
+        for (int d = SURTR_LANES / 2; d >= 1; d >>= 1) { const double o2 = __shfl_down(r2, d, SURTR_LANES); r2 = o2 > r2 ? o2 : r2; }
+        __syncthreads();
+        if (lane == 0) L.r2 = r2;
+        __syncthreads();
     };
-    if (lane == 0) radius2();
-    __syncthreads();
+    radius2();
     for (uint32_t base = 0; base < C; base += SURTR_LANES)
     {
         const uint32_t o = base + lane;
@@ -281,12 +329,13 @@ __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, u
             __syncthreads();
             if (lane == first)
             {
-                cut_cell_serial(L, n, cc);
+                L.cut_n = n; L.cut_c = cc;
                 if (L.ng < SURTR_CELL_G) { L.gid[L.ng] = (int32_t)o; L.gn[L.ng] = n; L.gc[L.ng] = cc; ++L.ng; }
                 else L.err = SURTR_E_CAPACITY;
-                radius2();
             }
             __syncthreads();
+            cut_cell_wave(L, L.cut_n, L.cut_c);      // (all lanes: the plane of the lowest touching seed)
+            radius2();
             if (lane <= first) cand = false;
         }
     }

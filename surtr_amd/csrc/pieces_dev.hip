@@ -433,7 +433,10 @@ int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_out
     for (uint32_t k = 0; k < c.n_frag; ++k)
     {
         if (keep && !keep[k]) continue;
-        if (fr[k].mv_n < 4 || fr[k].cv_n < 4) return SURTR_E_INVALID;
+        // fewer than four vertices is no solid (Src/Poly.cpp:497-499; a Convex the refit clipped away): with an explicit
+        // mask that is the caller's error, without one such fragments are left out (the reference's m_fractureTask would get
+        // nothing out of them either, Src/Surtr.cpp:1466-1468)
+        if (fr[k].mv_n < 4 || fr[k].cv_n < 4) { if (keep) return SURTR_E_INVALID; continue; }
         frag.push_back(k);
         vo[0].push_back(vo[0].back() + fr[k].mv_n); ho[0].push_back(ho[0].back() + fr[k].mh_n);
         vo[1].push_back(vo[1].back() + fr[k].cv_n); ho[1].push_back(ho[1].back() + fr[k].ch_n);
@@ -470,6 +473,33 @@ int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_out
     set_piece_stats(ctx, n, vo[0].data(), ho[0].data(), vo[1].data(), ho[1].data());
     ctx->have_event = true;       // the event's fragments are still in the arena: they can be downloaded after this call
     return finish_upload(ctx, n, false);
+}
+
+// scale / shift of every group = extent / centre of the Mesh box of the piece with the same number (k_piece_box left it in S.box)
+__global__ void k_group_boxes(uint32_t n, const float* __restrict__ box, float* __restrict__ scale3, float* __restrict__ shift3)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    for (int c = 0; c < 3; ++c)
+    {
+        const float lo = box[6 * g + c], hi = box[6 * g + 3 + c];
+        scale3[3 * g + c] = hi - lo;                                           // Vector3(maxX - minX, ...) (Src/Surtr.cpp:1800)
+        shift3[3 * g + c] = (float)(((double)hi + (double)lo) / 2.0);          // BBCenter: double arithmetic, narrowed (:1771)
+    }
+}
+
+int surtr_place_cells_in_pieces(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off)
+{
+    if (!ctx || !n_groups || !group_cell_off) return SURTR_E_INVALID;
+    if (!ctx->n_pieces || !ctx->d_v012) return SURTR_E_STATE;
+    if (n_groups != ctx->n_pieces) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    int rc = pool_reserve(ctx, &ctx->d_group_xf, ctx->c_group_xf, (size_t)6 * n_groups);
+    if (rc) return rc;
+    float* sc = ctx->d_group_xf; float* sh = sc + 3 * (size_t)n_groups;
+    hipLaunchKernelGGL(k_group_boxes, dim3((n_groups + 255) / 256), dim3(256), 0, ctx->stream, n_groups, ctx->mset.box, sc, sh);
+    HIPCHK(hipGetLastError());
+    return surtr_place_cells_groups_dev(ctx, n_groups, group_cell_off, sc, sh);
 }
 
 int surtr_download_piece(surtr_ctx* ctx, uint32_t piece, int set, uint32_t* out_nv, uint32_t* out_nh, float* out_pos, uint32_t* out_off, int32_t* out_nbr)

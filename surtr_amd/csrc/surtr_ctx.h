@@ -219,6 +219,7 @@ struct surtr_ctx
     CellBuffers cells;               // surtr_build_cells
     PieceSet mset, cset;             // the resident pieces: Mesh and Convex solids + what the pre-pass derives from them (pieces_dev.hip)
     uint32_t* d_upload_err = nullptr; uint32_t cap_outside = 0;
+    float* d_group_xf = nullptr; size_t c_group_xf = 0;  // surtr_place_cells_in_pieces: per-group scale / shift
     float* d_world = nullptr; size_t c_world = 0;        // surtr_transform_pieces: the world matrices
     char* sort_tmp = nullptr; size_t c_sort_tmp = 0;      // radix-sort scratch of the Morton sort
     uint32_t* d_from = nullptr; size_t c_from = 0;       // surtr_pieces_from_event: fragment list and offsets
@@ -243,6 +244,7 @@ struct surtr_ctx
     uint32_t* d_frag_status = nullptr;      // per fragment: SURTR_OK or why it has no triangles (u32[cap_frags])
     uint2* d_scanblk = nullptr; uint32_t cap_scanblk = 0;
     surtr_counts* d_counts = nullptr;
+    uint32_t* d_face_group = nullptr; uint32_t cap_face_group = 0;      // surtr_place_cells_groups: group of every pattern face
     uint8_t* d_outside = nullptr;
     std::vector<uint8_t> last_outside;       // the `outside` mask of the last event (empty: none), for surtr_event_regroup
     uint2* d_pair_list = nullptr; uint32_t cap_pair_list = 0;
@@ -278,3 +280,6 @@ struct surtr_ctx
     } while (0)
 
 static inline void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+// placement of cell groups with per-group scale / shift already in device memory (surtr_hip.hip)
+extern "C" int surtr_place_cells_groups_dev(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* d_scale3, const float* d_shift3);

@@ -1966,10 +1966,10 @@ void surtr_destroy(surtr_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     ctx->mset.release(); ctx->cset.release(); ctx->cells.release();
-    free_dev(ctx->d_upload_err); free_dev(ctx->d_world); free_dev(ctx->sort_tmp); free_dev(ctx->d_from);
+    free_dev(ctx->d_upload_err); free_dev(ctx->d_group_xf); free_dev(ctx->d_world); free_dev(ctx->sort_tmp); free_dev(ctx->d_from);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
-    free_dev(ctx->d_pair_order);
+    free_dev(ctx->d_pair_order); free_dev(ctx->d_face_group);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
 #ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -2431,9 +2431,10 @@ int surtr_fracture_pairs_async(surtr_ctx* ctx, uint32_t n_pairs, const uint32_t*
     return launch_event(ctx, 0, n_pairs, ctx->d_pair_list, nullptr, flags);
 }
 
-int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* scale3, const float* translate3)
+// face -> group table of the pattern (cached per pattern) and the placement kernel; scale3 / shift3 are device arrays
+int surtr_place_cells_groups_dev(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* d_scale3, const float* d_shift3)
 {
-    if (!ctx || !n_groups || !group_cell_off || !scale3 || !translate3) return SURTR_E_INVALID;
+    if (!ctx || !n_groups || !group_cell_off || !d_scale3 || !d_shift3) return SURTR_E_INVALID;
     if (!ctx->d_v012) return SURTR_E_STATE;
     if (group_cell_off[0] != 0 || group_cell_off[n_groups] != ctx->n_cells) return SURTR_E_INVALID;
     (void)hipSetDevice(ctx->device);
@@ -2445,21 +2446,32 @@ int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* 
         for (uint32_t c = group_cell_off[g]; c < group_cell_off[g + 1]; ++c)
             for (uint32_t f = ctx->h_plane_off[c]; f < ctx->h_plane_off[c + 1]; ++f) face_group[f] = g;
     }
-    uint32_t* d_fg = nullptr; float *d_s = nullptr, *d_t = nullptr;
-    auto cleanup = [&]() { free_dev(d_fg); free_dev(d_s); free_dev(d_t); };
-    if (hipMalloc((void**)&d_fg, (size_t)std::max(nf, 1u) * 4) != hipSuccess || hipMalloc((void**)&d_s, (size_t)n_groups * 12) != hipSuccess ||
-        hipMalloc((void**)&d_t, (size_t)n_groups * 12) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
-    hipError_t e = hipMemcpy(d_fg, face_group.data(), (size_t)nf * 4, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_s, scale3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_t, translate3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { cleanup(); return SURTR_E_HIP; }
+    if (ctx->cap_face_group < std::max(nf, 1u))
+    {
+        free_dev(ctx->d_face_group); ctx->d_face_group = nullptr; ctx->cap_face_group = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_face_group, (size_t)(nf + nf / 4 + 64) * 4));
+        ctx->cap_face_group = nf + nf / 4 + 64;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->d_face_group, face_group.data(), (size_t)nf * 4, hipMemcpyHostToDevice, ctx->stream));
     if (nf)
-        hipLaunchKernelGGL(k_place_cells_groups, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, nf, ctx->d_v012, d_fg, d_s, d_t, ctx->d_planes);
-    e = hipStreamSynchronize(ctx->stream);
-    cleanup();
-    if (e != hipSuccess || hipGetLastError() != hipSuccess) return SURTR_E_HIP;
+        hipLaunchKernelGGL(k_place_cells_groups, dim3((nf + 255) / 256), dim3(256), 0, ctx->stream, nf, ctx->d_v012, ctx->d_face_group, d_scale3, d_shift3, ctx->d_planes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));      // face_group is a stack-owned staging buffer
     ctx->planes_ready = true;
     return SURTR_OK;
+}
+
+int surtr_place_cells_groups(surtr_ctx* ctx, uint32_t n_groups, const uint32_t* group_cell_off, const float* scale3, const float* translate3)
+{
+    if (!ctx || !n_groups || !group_cell_off || !scale3 || !translate3) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, (size_t)n_groups * 24) != hipSuccess) return SURTR_E_HIP;
+    hipError_t e = hipMemcpy(d, scale3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 3 * (size_t)n_groups, translate3, (size_t)n_groups * 12, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? surtr_place_cells_groups_dev(ctx, n_groups, group_cell_off, d, d + 3 * (size_t)n_groups) : SURTR_E_HIP;
+    free_dev(d);
+    return rc;
 }
 
 int surtr_event_refit(surtr_ctx* ctx)

@@ -223,6 +223,10 @@ class Engine:
         assert s.shape[0] == go.shape[0] - 1 == t.shape[0]
         self._ck(lib().surtr_place_cells_groups(self._h, ctypes.c_uint32(s.shape[0]), _p(go), _p(s), _p(t)))
 
+    def place_cells_in_pieces(self, group_cell_off):
+        go = np.ascontiguousarray(group_cell_off, np.uint32)
+        self._ck(lib().surtr_place_cells_in_pieces(self._h, ctypes.c_uint32(go.shape[0] - 1), _p(go)))
+
     def fracture_pairs(self, pair_cell, pair_piece, flags=EVT_REFIT | EVT_RENDER):
         pc = np.ascontiguousarray(pair_cell, np.uint32)
         pp = np.ascontiguousarray(pair_piece, np.uint32)

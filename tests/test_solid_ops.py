@@ -140,6 +140,25 @@ def check_pieces_from_event(E, oracle):
         got = eng.download()
     finally:
         eng.close()
+    # the same chain with nothing but sizes crossing the bus: cells built on the device (one diagram per piece), placed over
+    # the pieces' boxes taken on the device
+    eng = E.Engine(0)
+    try:
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        eng.upload_pattern(sc["face_off"], sc["v012"])
+        eng.place_cells(sc["scale"], sc["translate"])
+        eng.fracture_event(0, sc["n_cells"], flags=1)
+        n = eng.pieces_from_event(keep)
+        seeds = np.concatenate([scenes.uniform_seeds(5, scenes.SEED + p) for p in range(n)])
+        go = np.arange(0, 5 * n + 1, 5, dtype=np.uint32)
+        eng.build_cells(seeds, go)
+        eng.place_cells_in_pieces(go)
+        eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"])
+        got2 = eng.download()
+    finally:
+        eng.close()
+    for k in got:
+        assert np.array_equal(got[k], got2[k]), k
     planes2 = np.concatenate([oracle.place_cells(rs["v012"][rs["face_off"][rs["group_cell_off"][g]]:rs["face_off"][rs["group_cell_off"][g + 1]]],
                                                  rs["scales"][g], rs["shifts"][g]) for g in range(len(kept))])
     parts = []
