@@ -9,14 +9,17 @@ from oracle import oracle as O
 from surtr_amd import engine as E, scenes as S, meshgen as G
 from helpers import assert_event_equal
 
-def random_scene(rng):
-    kind = rng.integers(0, 4)
+def random_scene(rng, eng=None):
+    kind = rng.integers(0, 5)
     if kind == 0:
         v, t = G.bumpy_torus(int(rng.integers(20, 180)), int(rng.integers(12, 120)), R=float(rng.uniform(0.6, 1.5)), r0=float(rng.uniform(0.15, 0.4)))
     elif kind == 1:
         v, t = G.blob(int(rng.integers(2, 5)), scale=float(rng.uniform(0.5, 80.0)))
     elif kind == 2:
         v, t = G.cube(float(rng.uniform(0.3, 5.0)))
+    elif kind == 4:      # deep lobes: several islands per cell, non-convex faces
+        v, t = G.urchin(int(rng.integers(3, 5)), scale=float(rng.uniform(0.5, 80.0)), spikes=int(rng.integers(6, 40)),
+                        length=float(rng.uniform(0.6, 1.8)), width=float(rng.uniform(0.08, 0.2)))
     else:
         v, t = G.blob(3, scale=1.0)
         v2, t2 = G.cube(0.4)
@@ -24,7 +27,8 @@ def random_scene(rng):
     v = (v + rng.uniform(-1, 1, 3).astype(np.float32) * np.float32(rng.uniform(0, 3))).astype(np.float32)
     n_cells = int(rng.choice([3, 8, 17, 64, 150, 400]))
     seeds = S.uniform_seeds(n_cells, int(rng.integers(1, 1 << 30)))
-    return S.make_scene(v, t, n_cells, seeds=seeds), kind
+    # every other scene gets its Voronoi cells from the device builder (surtr_build_cells) instead of the host one
+    return S.make_scene(v, t, n_cells, seeds=seeds, eng=eng if rng.integers(0, 2) else None), kind
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
@@ -33,7 +37,7 @@ def main():
     bad = 0; undefined = 0
     t0 = time.time()
     for case in range(n):
-        sc, kind = random_scene(rng)
+        sc, kind = random_scene(rng, eng)
         use_ach = bool(rng.integers(0, 2))
         if use_ach:
             sc["convex"], _ = S.ach_convex(eng, sc["mesh"]["pos"])
