@@ -60,7 +60,8 @@ __device__ unsigned long long g_stamp[96];
 #define STAMP_DECL unsigned long long st_t0 = __builtin_readcyclecounter(); unsigned long long st_t1
 #ifdef SURTR_STAMP_SMALL
 // one-wave kernels: accumulate in LDS only (thousands of workgroups on one global counter would measure the atomics)
-#define STAMP(i) do { if (threadIdx.x == 0 && STAMP_WHO) { st_t1 = __builtin_readcyclecounter(); sh.ph[(i) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
+// (phases 76..78 of the selection go to slots 1..3, which the one-wave kernels' load_whole path leaves free)
+#define STAMP(i) do { if (threadIdx.x == 0 && STAMP_WHO) { st_t1 = __builtin_readcyclecounter(); sh.ph[((i) >= 76 && (i) <= 78 ? (i) - 75 : (i)) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
 #else
 #define STAMP(i) do { if (threadIdx.x == 0 && STAMP_WHO) { st_t1 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[i], st_t1 - st_t0); sh.ph[(i) & 15] += st_t1 - st_t0; st_t0 = st_t1; } } while (0)
 #endif
