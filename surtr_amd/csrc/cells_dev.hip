@@ -94,7 +94,7 @@ __device__ void cut_cell_wave(CellLds& L, const D3 n, const double cc)
 #ifdef SURTR_EMUL
         carry += inc.x;
 #else
-        carry += (uint32_t)__shfl((int)inc.x, SURTR_LANES - 1, SURTR_LANES);
+        carry += lane_bcast(inc.x, SURTR_LANES - 1u);
 #endif
     }
     const int n1 = n0 + (int)carry;
@@ -149,7 +149,7 @@ __device__ void cut_cell_wave(CellLds& L, const D3 n, const double cc)
 #ifdef SURTR_EMUL
         carry += inc.x;
 #else
-        carry += (uint32_t)__shfl((int)inc.x, SURTR_LANES - 1, SURTR_LANES);
+        carry += lane_bcast(inc.x, SURTR_LANES - 1u);
 #endif
     }
     const int live = (int)carry;

@@ -111,6 +111,26 @@ __device__ unsigned long long g_stamp[96];
 
 namespace surtr {
 
+// Cross-lane moves without the LDS crossbar.  `__shfl*` compiles to ds_bpermute_b32 on gfx950 (an LDS-pipeline round trip per
+// call: six dependent ones per wave scan); the data-parallel-primitive modifiers move data between lanes inside the VALU.
+#ifndef SURTR_EMUL
+// lane i <- lane (i - N) of its row of 16 (row_shr:N), lanes without a source keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_move(uint32_t old, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, ROW_MASK, 0xF, false);
+}
+// value of a wave-uniform lane, through a scalar register (v_readlane_b32)
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)SURTR_UNIFORM(lane)); }
+__device__ __forceinline__ float lane_bcast(float v, uint32_t lane) { return __uint_as_float(lane_bcast(__float_as_uint(v), lane)); }
+__device__ __forceinline__ int lane_bcast(int v, uint32_t lane) { return (int)lane_bcast((uint32_t)v, lane); }
+#else
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t) { return v; }
+__device__ __forceinline__ float lane_bcast(float v, uint32_t) { return v; }
+__device__ __forceinline__ int lane_bcast(int v, uint32_t) { return v; }
+#endif
+
+
 // hist[f] += number of active lanes holding f: one LDS atomic per distinct value per wave instead of one per lane.
 __device__ __forceinline__ void wave_hist_add(uint32_t* hist, uint32_t f, bool active)
 {
@@ -121,7 +141,7 @@ __device__ __forceinline__ void wave_hist_add(uint32_t* hist, uint32_t f, bool a
     while (todo)
     {
         const int leader = __builtin_ctzll(todo);
-        const uint32_t f0 = (uint32_t)__shfl((int)f, leader, 64);
+        const uint32_t f0 = lane_bcast(f, (uint32_t)leader);
         const unsigned long long same = __ballot(active && f == f0);
         if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[f0], (uint32_t)__builtin_popcountll(same));
         todo &= ~same;
@@ -228,16 +248,18 @@ __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> SURTR_LSH;
 __device__ __forceinline__ uint32_t group_size() { return blockDim.x; }
 __device__ __forceinline__ uint32_t group_waves() { return blockDim.x >> SURTR_LSH; }
 
+// Inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the row totals
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six VALU operations per value.
 __device__ __forceinline__ uint2 wave_incl_scan2(uint2 v)
 {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < SURTR_LANES; d <<= 1)
-    {
-        uint32_t a = __shfl_up(v.x, d, SURTR_LANES);
-        uint32_t b = __shfl_up(v.y, d, SURTR_LANES);
-        if (l >= (uint32_t)d) { v.x += a; v.y += b; }
-    }
+#ifndef SURTR_EMUL
+    v.x += dpp_move<0x111, 0xF>(0u, v.x); v.y += dpp_move<0x111, 0xF>(0u, v.y);
+    v.x += dpp_move<0x112, 0xF>(0u, v.x); v.y += dpp_move<0x112, 0xF>(0u, v.y);
+    v.x += dpp_move<0x114, 0xF>(0u, v.x); v.y += dpp_move<0x114, 0xF>(0u, v.y);
+    v.x += dpp_move<0x118, 0xF>(0u, v.x); v.y += dpp_move<0x118, 0xF>(0u, v.y);
+    v.x += dpp_move<0x142, 0xA>(0u, v.x); v.y += dpp_move<0x142, 0xA>(0u, v.y);
+    v.x += dpp_move<0x143, 0xC>(0u, v.x); v.y += dpp_move<0x143, 0xC>(0u, v.y);
+#endif
     return v;
 }
 
@@ -621,7 +643,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             {
                 uint32_t base = 0;
                 if (l == 0) base = atomicAdd(&sh.misc[3], (uint32_t)__builtin_popcountll(mn));
-                base = (uint32_t)__shfl((int)base, 0, SURTR_LANES);
+                base = lane_bcast(base, 0u);
                 if (need) needy[base + (uint32_t)__builtin_popcountll(mn & ((1ull << l) - 1ull))] = v | (f << 24);
             }
         }
@@ -882,7 +904,7 @@ __device__ inline void select_write(const uint8_t* arr, uint32_t val, uint32_t n
 #ifdef SURTR_EMUL
         run += s2.x;
 #else
-        run += (uint32_t)__shfl((int)s2.x, SURTR_LANES - 1, SURTR_LANES);
+        run += lane_bcast(s2.x, SURTR_LANES - 1u);
 #endif
     }
     __syncthreads();
@@ -1204,7 +1226,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
 #ifdef SURTR_EMUL
                 run += s2.x;
 #else
-                run += (uint32_t)__shfl((int)s2.x, SURTR_LANES - 1, SURTR_LANES);
+                run += lane_bcast(s2.x, SURTR_LANES - 1u);
 #endif
                 if (i < nC && c.x)
                 {

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "surtr_ctx.h"
@@ -1008,16 +1009,42 @@ struct ArgD { double v; uint32_t i; };
 template <class T, class A>
 __device__ static A wg_argmax(A mine, A* slots /* shared, SURTR_NWAVE */)
 {
-    // wave reduce
-    for (int d = SURTR_LANES / 2; d >= 1; d >>= 1)
-    {
-        A o;
-        o.v = __shfl_down(mine.v, d, SURTR_LANES);
-        o.i = __shfl_down(mine.i, d, SURTR_LANES);
+    // wave reduce ("larger value, then smaller index" is associative and commutative): the scan pattern of wave_incl_scan2
+    // with that operator leaves the result in the last lane; lanes without a source receive the invalid index
+#ifndef SURTR_EMUL
+    auto step = [&](auto mv) {
+        A o = mv(mine);
         if (o.i != 0xFFFFFFFFu && (mine.i == 0xFFFFFFFFu || o.v > mine.v || (o.v == mine.v && o.i < mine.i))) mine = o;
-    }
+    };
+    auto mover = [](auto ctrl_tag, auto mask_tag) {
+        return [](A a) {
+            constexpr int CTRL = decltype(ctrl_tag)::value, MASK = decltype(mask_tag)::value;
+            A o;
+            o.i = dpp_move<CTRL, MASK>(0xFFFFFFFFu, a.i);
+            if constexpr (sizeof(T) == 4)
+            {
+                uint32_t b; memcpy(&b, &a.v, 4);
+                b = dpp_move<CTRL, MASK>(0u, b);
+                memcpy(&o.v, &b, 4);
+            }
+            else
+            {
+                uint32_t b[2]; memcpy(b, &a.v, 8);
+                b[0] = dpp_move<CTRL, MASK>(0u, b[0]); b[1] = dpp_move<CTRL, MASK>(0u, b[1]);
+                memcpy(&o.v, b, 8);
+            }
+            return o;
+        };
+    };
+    step(mover(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{}));
+    step(mover(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{}));
+    step(mover(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{}));
+    step(mover(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{}));
+    step(mover(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}));
+    step(mover(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}));
+#endif
     __syncthreads();
-    if (lane_id() == 0) slots[wave_id()] = mine;
+    if (lane_id() == SURTR_LANES - 1u) slots[wave_id()] = mine;
     __syncthreads();
     A best = slots[0];
     for (uint32_t q = 1; q < group_waves(); ++q)
@@ -1267,9 +1294,15 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
     const bool mine = lane < N;
     const int32_t vid = loop[mine ? lane : 0];
     const float x = pos[3 * vid], y = pos[3 * vid + 1], z = pos[3 * vid + 2];
-    auto bx = [&](int i) { return __shfl(x, i, 64); };
-    auto by = [&](int i) { return __shfl(y, i, 64); };
-    auto bz = [&](int i) { return __shfl(z, i, 64); };
+    // (every index below is wave-uniform: broadcasts go through scalar registers, not the LDS crossbar)
+#ifdef SURTR_EAR_SHFL
+#define EAR_BCAST(v, i) __shfl(v, i, 64)
+#else
+#define EAR_BCAST(v, i) lane_bcast(v, (uint32_t)(i))
+#endif
+    auto bx = [&](int i) { return EAR_BCAST(x, i); };
+    auto by = [&](int i) { return EAR_BCAST(y, i); };
+    auto bz = [&](int i) { return EAR_BCAST(z, i); };
     const float ax0 = bx(0), ay0 = by(0), az0 = bz(0);
     float nx, ny, nz;
     {
@@ -1297,15 +1330,17 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
     };
     bool rfx = false;
     {
-        const float px_ = bx(prv), py_ = by(prv), pz_ = bz(prv), qx = bx(nxt), qy = by(nxt), qz = bz(nxt);
+        // (the one place where every lane reads ANOTHER lane of its own choosing: a real shuffle)
+        const float px_ = __shfl(x, prv, 64), py_ = __shfl(y, prv, 64), pz_ = __shfl(z, prv, 64);
+        const float qx = __shfl(x, nxt, 64), qy = __shfl(y, nxt, 64), qz = __shfl(z, nxt, 64);
         rfx = mine && !right_of(px_, py_, pz_, x, y, z, qx, qy, qz);
     }
     int skipped = 0, left = N, cur = 0;
     uint32_t at = 0;
     while (left > 3)
     {
-        const int p = __shfl(prv, cur, 64), n = __shfl(nxt, cur, 64);
-        const bool cur_reflex = __shfl((int)rfx, cur, 64) != 0;
+        const int p = EAR_BCAST(prv, cur), n = EAR_BCAST(nxt, cur);
+        const bool cur_reflex = EAR_BCAST((int)rfx, cur) != 0;
         bool ear = !cur_reflex;
         if (ear)
         {
@@ -1329,7 +1364,7 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
             if (lane == n) prv = p;
             // reflex flags of the two neighbours, only if they were reflex (:885-893)
             // (all broadcasts are done by the whole wave; only the two lanes use them)
-            const int np = __shfl(prv, p, 64), nn = __shfl(nxt, n, 64);
+            const int np = EAR_BCAST(prv, p), nn = EAR_BCAST(nxt, n);
             const float npx = bx(np), npy = by(np), npz = bz(np), nnx = bx(nn), nny = by(nn), nnz = bz(nn);
             const float ppx = bx(p), ppy = by(p), ppz = bz(p), qqx = bx(n), qqy = by(n), qqz = bz(n);
             if (lane == p && rfx) rfx = !right_of(npx, npy, npz, x, y, z, qqx, qqy, qqz);
@@ -1340,7 +1375,7 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
         cur = n;
     }
     {
-        const int p = __shfl(prv, cur, 64), n = __shfl(nxt, cur, 64);
+        const int p = EAR_BCAST(prv, cur), n = EAR_BCAST(nxt, cur);
         if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
     }
     return at + 3;
