@@ -222,7 +222,7 @@ struct SolidIn
     const float* rad;       // per vertex: radius of a ball around it holding every vertex of its incident faces (nullptr = unknown)
     // spatially sorted copy for the pre-pass (nullptr = absent): sorted index i is vertex perm[i]; bsph[b] bounds
     // the balls of the SURTR_SB vertices of sorted group b (centre xyz, radius w)
-    const uint32_t* perm; const float* pos_s; const float* rad_s; const float4* bsph;
+    const uint32_t* perm; const float4* posr_s; const float4* bsph;      // posr_s: (x, y, z, ball radius) of sorted vertex i: one 16-byte load
 };
 
 __device__ __forceinline__ float plane_dist(const float4 pl, float x, float y, float z)
@@ -572,8 +572,8 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             if (sorted)
             {
                 id4[g] = in.perm[ii];
-                px4[g] = in.pos_s[3 * ii]; py4[g] = in.pos_s[3 * ii + 1]; pz4[g] = in.pos_s[3 * ii + 2];
-                rv4[g] = in.rad_s[ii];
+                const float4 pr = in.posr_s[ii];
+                px4[g] = pr.x; py4[g] = pr.y; pz4[g] = pr.z; rv4[g] = pr.w;
             }
             else
             {

@@ -164,19 +164,18 @@ __global__ void k_piece_keys(uint32_t V, uint32_t n, const uint32_t* __restrict_
 
 // Sorted copy: sorted slot i of piece p holds vertex perm[i] (piece-local), its position and its ball radius.
 __global__ void k_piece_sorted(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const float* __restrict__ pos,
-                               const float* __restrict__ rad, const uint32_t* __restrict__ perm, float* __restrict__ pos_s, float* __restrict__ rad_s)
+                               const float* __restrict__ rad, const uint32_t* __restrict__ perm, float4* __restrict__ posr_s)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
     const uint32_t p = piece_of(vo, n, i);
     const size_t g = (size_t)vo[p] + perm[i];
-    pos_s[3 * (size_t)i] = pos[3 * g]; pos_s[3 * (size_t)i + 1] = pos[3 * g + 1]; pos_s[3 * (size_t)i + 2] = pos[3 * g + 2];
-    rad_s[i] = rad[g];
+    posr_s[i] = make_float4(pos[3 * g], pos[3 * g + 1], pos[3 * g + 2], rad[g]);
 }
 
 // One bounding sphere per SURTR_SB consecutive sorted vertices of a piece: it holds their balls (pre-pass A0).
 __global__ void k_piece_spheres(uint32_t NB, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ bo,
-                                const float* __restrict__ pos_s, const float* __restrict__ rad_s, float4* __restrict__ bsph)
+                                const float4* __restrict__ posr_s, float4* __restrict__ bsph)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= NB) return;
@@ -186,16 +185,17 @@ __global__ void k_piece_spheres(uint32_t NB, uint32_t n, const uint32_t* __restr
     for (uint32_t i = i0; i < i1; ++i)
         for (int c = 0; c < 3; ++c)
         {
-            const double x = pos_s[3 * (size_t)(a + i) + c];
+            const float4 pr = posr_s[a + i];
+            const double x = c == 0 ? pr.x : (c == 1 ? pr.y : pr.z);
             blo[c] = x < blo[c] ? x : blo[c]; bhi[c] = x > bhi[c] ? x : bhi[c];
         }
     const float cx = (float)((blo[0] + bhi[0]) / 2), cy = (float)((blo[1] + bhi[1]) / 2), cz = (float)((blo[2] + bhi[2]) / 2);
     double R = 0;
     for (uint32_t i = i0; i < i1; ++i)
     {
-        const double dx = pos_s[3 * (size_t)(a + i)] - (double)cx, dy = pos_s[3 * (size_t)(a + i) + 1] - (double)cy,
-                     dz = pos_s[3 * (size_t)(a + i) + 2] - (double)cz;
-        const double d = sqrt(dx * dx + dy * dy + dz * dz) + (double)rad_s[a + i];
+        const float4 pr = posr_s[a + i];
+        const double dx = pr.x - (double)cx, dy = pr.y - (double)cy, dz = pr.z - (double)cz;
+        const double d = sqrt(dx * dx + dy * dy + dz * dz) + (double)pr.w;
         R = d > R ? d : R;
     }
     bsph[g] = make_float4(cx, cy, cz, (float)(R * 1.000001) + 1e-30f);
@@ -254,7 +254,7 @@ int reserve_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, uint32_t H,
     int rc = 0;
 #define R(ptr, cap, need) do { rc = pool_reserve(ctx, &S.ptr, S.cap, (size_t)(need)); if (rc) return rc; } while (0)
     R(pos, c_pos, 3 * (size_t)V + 3); R(loff, c_loff, (size_t)V + 1); R(llen, c_llen, V); R(nbr, c_nbr, (size_t)H + 1); R(vo, c_vo, n + 1);
-    R(tri, c_tri, V); R(rad, c_rad, V); R(perm, c_perm, V); R(pos_s, c_pos_s, 3 * (size_t)V + 3); R(rad_s, c_rad_s, V);
+    R(tri, c_tri, V); R(rad, c_rad, V); R(perm, c_perm, V); R(posr_s, c_posr_s, (size_t)V + 1);
     R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, V);
 #undef R
     return SURTR_OK;
@@ -288,8 +288,8 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
         for (uint32_t i = 0; i < V; ++i) S.perm[i] = S.val[order[i]];
     }
 #endif
-    hipLaunchKernelGGL(k_piece_sorted, gridV, blk, 0, st, V, n, S.vo, S.pos, S.rad, S.perm, S.pos_s, S.rad_s);
-    if (NB) hipLaunchKernelGGL(k_piece_spheres, dim3((NB + 255) / 256), blk, 0, st, NB, n, S.vo, S.bo, S.pos_s, S.rad_s, S.bsph);
+    hipLaunchKernelGGL(k_piece_sorted, gridV, blk, 0, st, V, n, S.vo, S.pos, S.rad, S.perm, S.posr_s);
+    if (NB) hipLaunchKernelGGL(k_piece_spheres, dim3((NB + 255) / 256), blk, 0, st, NB, n, S.vo, S.bo, S.posr_s, S.bsph);
     HIPCHK(hipGetLastError());
     return SURTR_OK;
 }

@@ -84,9 +84,9 @@ struct Arena
 struct Pieces
 {
     const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri; const float* mrad;
-    const uint32_t* mperm; const float* mpos_s; const float* mrad_s; const float4* mbsph; const uint32_t* mbo;
+    const uint32_t* mperm; const float4* mposr_s; const float4* mbsph; const uint32_t* mbo;
     const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri; const float* crad;
-    const uint32_t* cperm; const float* cpos_s; const float* crad_s; const float4* cbsph; const uint32_t* cbo;
+    const uint32_t* cperm; const float4* cposr_s; const float4* cbsph; const uint32_t* cbo;
     uint32_t n;
 };
 
@@ -155,13 +155,13 @@ struct PieceSet
 {
     float* pos = nullptr; uint32_t* loff = nullptr; uint32_t* llen = nullptr; int32_t* nbr = nullptr; uint32_t* vo = nullptr;
     uint8_t* tri = nullptr; float* rad = nullptr;
-    uint32_t* perm = nullptr; float* pos_s = nullptr; float* rad_s = nullptr; float4* bsph = nullptr; uint32_t* bo = nullptr;
+    uint32_t* perm = nullptr; float4* posr_s = nullptr; float4* bsph = nullptr; uint32_t* bo = nullptr;
     float* box = nullptr; unsigned long long* key = nullptr; unsigned long long* key2 = nullptr; uint32_t* val = nullptr;    // Morton sort
-    size_t c_pos = 0, c_loff = 0, c_llen = 0, c_nbr = 0, c_vo = 0, c_tri = 0, c_rad = 0, c_perm = 0, c_pos_s = 0, c_rad_s = 0, c_bsph = 0,
+    size_t c_pos = 0, c_loff = 0, c_llen = 0, c_nbr = 0, c_vo = 0, c_tri = 0, c_rad = 0, c_perm = 0, c_posr_s = 0, c_bsph = 0,
            c_bo = 0, c_box = 0, c_key = 0, c_key2 = 0, c_val = 0;
     void release()
     {
-        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, pos_s, rad_s, bsph, bo, box, key, key2, val};
+        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val};
         for (void* p : all) if (p) (void)hipFree(p);
         *this = PieceSet();
     }

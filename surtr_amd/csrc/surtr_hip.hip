@@ -549,7 +549,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             __syncthreads();
             const uint32_t c0 = P.cvo[piece];
             SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
-                        P.cperm + c0, P.cpos_s + 3 * (size_t)c0, P.crad_s + c0, P.cbsph + P.cbo[piece]};
+                        P.cperm + c0, P.cposr_s + c0, P.cbsph + P.cbo[piece]};
             err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
                 if (T.nLive == 0) return 0;
                 return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
         for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
         __syncthreads();
         SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, V, P.mtri + m0, P.mrad + m0,
-                    P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+                    P.mperm + m0, P.mposr_s + m0, P.mbsph + P.mbo[piece]};
         STAMP(70);
         const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
         unsigned long long* bmask = nbV <= SURTR_PREP_NB ? lmask : gmask;
@@ -782,7 +782,7 @@ __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t p
     PairRec rec = pairs[p];
     const uint32_t m0 = P.mvo[piece];
     SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
-                P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+                P.mperm + m0, P.mposr_s + m0, P.mbsph + P.mbo[piece]};
     auto consume = [&](auto& T) -> int {
         if (T.nLive == 0) return 0;
         return park_mesh_islands(T, sh, A, rec);
@@ -849,7 +849,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         __syncthreads();
         const uint32_t m0 = P.mvo[piece];
         SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
-                    P.mperm + m0, P.mpos_s + 3 * (size_t)m0, P.mrad_s + m0, P.mbsph + P.mbo[piece]};
+                    P.mperm + m0, P.mposr_s + m0, P.mbsph + P.mbo[piece]};
         auto consume = [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_mesh_islands(T, sh, A, rec);
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
 #if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
         if (tid == 0) { const unsigned long long r2 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[94], r1 - r0); atomicAdd(&g_stamp[95], r2 - r1); }
 #endif
-        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
         int err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
@@ -2305,8 +2305,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         d_out = ctx->d_outside;
     }
     const PieceSet& M = ctx->mset; const PieceSet& C = ctx->cset;
-    Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.pos_s, M.rad_s, M.bsph, M.bo,
-             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.pos_s, C.rad_s, C.bsph, C.bo, ctx->n_pieces};
+    Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.posr_s, M.bsph, M.bo,
+             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     const uint32_t* d_pair_order = nullptr;
     if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it
@@ -2883,7 +2883,7 @@ int surtr_clip_polyhedron(surtr_ctx* ctx, uint32_t nv, const float* pos, const u
     CK(hipMemcpy(d_llen, llen.data(), (size_t)nv * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(d_nbr, nbr, (size_t)H * 4, hipMemcpyHostToDevice));
     if (n_planes) CK(hipMemcpy(d_pl, planes, (size_t)n_planes * 16, hipMemcpyHostToDevice));
-    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    SolidIn in{d_pos, d_loff, d_llen, d_nbr, nv, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(k_clip_single, dim3(1), dim3(SURTR_WG), 0, ctx->stream, in, d_pl, n_planes, ctx->pool, d_opos, d_ooff, d_onbr,
                        d_ollen, capv, caph, d_res);
     CK(hipGetLastError());
