@@ -15,7 +15,7 @@ for r in csv.DictReader(open(f)):
         got[r["Kernel_Name"].split("(")[0]] = float(r["Counter_Value"]) * 1024.0
 out = {"source": "scripts/calib/fetch_calib.sh: rocprofv3 --pmc FETCH_SIZE on single-width reads of a 3 GiB buffer, MI355X",
        "k16_dwordx4_per_lane": got["k16"] / want["k16"], "k4_dword_per_lane": got["k4"] / want["k4"],
-       "k12_three_dwords_stride12": got["k12"] / want["k12"], "k2_ushort_per_lane": got["k2"] / want["k2"],
+       "k12_three_dwords_stride12": got["k12"] / want["k12"],
        "g4_random_dword_vs_useful_bytes": got["g4"] / want["g4_useful"], "g4_random_dword_vs_64B_lines": got["g4"] / want["g4_lines64"]}
 json.dump(out, open("gpurun_out/calib/fetch_calibration.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -30,8 +30,8 @@ clip, prep = res.get("k_clip_pairs", {}), res.get("k_prep_pairs", {})
 factor = 2.0
 note = "FETCH_SIZE x2 (the guide's gfx950 correction for wide streaming reads; the kernel's image loads are 16-B words)"
 if calib:
-    note += "; calibration on this box: dwordx4 %.2f, dword %.2f, 3 x dword stride 12 %.2f, ushort %.2f of the true bytes; random dword gathers are counted at %.2f of the 64-B lines they touch" % (
-        calib["k16_dwordx4_per_lane"], calib["k4_dword_per_lane"], calib["k12_three_dwords_stride12"], calib["k2_ushort_per_lane"], calib["g4_random_dword_vs_64B_lines"])
+    note += "; calibration on this box: dwordx4 %.2f, dword %.2f, 3 x dword stride 12 %.2f of the true bytes; random dword gathers are counted at %.2f of the 64-B lines they touch" % (
+        calib["k16_dwordx4_per_lane"], calib["k4_dword_per_lane"], calib["k12_three_dwords_stride12"], calib["g4_random_dword_vs_64B_lines"])
 rec = {"build_id": bench.kernel_build_id(),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/pmc.sh + scripts/pmc_summary.py) on `python bench.py --steps 2 --warmup 1`, MI355X; per-kernel means in " + os.path.basename(out),
        "k_clip_pairs_FETCH_SIZE_KB": clip.get("FETCH_SIZE"), "k_clip_pairs_WRITE_SIZE_KB": clip.get("WRITE_SIZE"),
