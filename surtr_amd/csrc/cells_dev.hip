@@ -11,9 +11,6 @@
 //   - faces: loops over unseen directed edges, generator = best-fitting plane, outward winding, start at the
 //     lexicographically smallest vertex, stable order by generator id (seeds ascending, then the walls -x +x -y +y -z +z).
 // The cells go straight into the context as the fracture pattern (v012 + face offsets = surtr_upload_pattern).
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#endif
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -91,11 +88,7 @@ __device__ void cut_cell_wave(CellLds& L, const D3 n, const double cc)
             for (int j = 0; j < 3; ++j) { const int k = L.ring[i][j]; if (k < n0 && !L.out[k]) ++cnt; }
         const uint2 inc = wave_incl_scan2(make_uint2(cnt, 0u));
         if (i < n0) L.id[i] = (int16_t)(carry + inc.x - cnt);          // first new vertex of cut vertex i (relative)
-#ifdef SURTR_EMUL
-        carry += inc.x;
-#else
         carry += lane_bcast(inc.x, SURTR_LANES - 1u);
-#endif
     }
     const int n1 = n0 + (int)carry;
     if (n1 > (int)SURTR_CELL_V) { if (lane == 0) L.err = SURTR_E_CAPACITY; __syncthreads(); return; }
@@ -146,11 +139,7 @@ __device__ void cut_cell_wave(CellLds& L, const D3 n, const double cc)
         const uint32_t keep = (i < n1 && (i >= n0 || !L.out[i])) ? 1u : 0u;
         const uint2 inc = wave_incl_scan2(make_uint2(keep, 0u));
         if (i < n1) L.id[i] = keep ? (int16_t)(carry + inc.x - 1u) : (int16_t)-1;
-#ifdef SURTR_EMUL
-        carry += inc.x;
-#else
         carry += lane_bcast(inc.x, SURTR_LANES - 1u);
-#endif
     }
     const int live = (int)carry;
     __syncthreads();
@@ -319,11 +308,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_build_cells(uint32_t n_cells, u
             // a seed farther than twice the cell's radius (with room for rounding) is on nobody's side: skip the exact test
             if (cand && L.err == 0 && d2 <= 4.0 * L.r2 * 1.00001 + 1e-18)
                 for (uint32_t i = 0; i < L.nv; ++i) if (plane_side(n, cc, L.p[i]) > 0) { touch = true; break; }
-#ifdef SURTR_EMUL
-            const unsigned long long mask = touch ? 1ull : 0ull;
-#else
             const unsigned long long mask = __ballot(touch);
-#endif
             if (mask == 0ull) break;
             const uint32_t first = (uint32_t)__builtin_ctzll(mask);
             __syncthreads();

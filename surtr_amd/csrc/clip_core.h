@@ -25,32 +25,25 @@
 // All arithmetic is float32 without contraction (compile with -ffp-contract=off);
 // see oracle/surtr_oracle.cpp for the SimpleMath semantics restated.
 #pragma once
-#ifdef SURTR_EMUL
-#include "hip_emul.h"        // tests/emul: single-lane CPU emulation, test infrastructure only
-#define SURTR_LANES 1
-#define SURTR_LSH 0
-#define SURTR_WG 1
-#define SURTR_NWAVE 1
-#else
-#include <hip/hip_runtime.h>
+#include <hip/hip_runtime.h>      // (the CPU test tier builds these sources with g++ against tests/emul/hip/hip_runtime.h: a single-lane
+                                  // emulation that sets SURTR_LANES = 1 and small capacities; test infrastructure only)
+#include <stdint.h>
+// wave / workgroup geometry (gfx950: wave64)
+#ifndef SURTR_LANES
 #define SURTR_LANES 64
 #define SURTR_LSH 6
+#endif
 #ifndef SURTR_WG
 #define SURTR_WG 256
 #endif
-#define SURTR_NWAVE (SURTR_WG / 64)   // the LARGEST group a kernel is launched with; smaller launches use fewer
-#endif
-#include <stdint.h>
-#ifdef SURTR_EMUL
-#include <cstdio>
-#define SURTR_DBG(...) fprintf(stderr, __VA_ARGS__)
-#else
+#define SURTR_NWAVE (SURTR_WG / SURTR_LANES)   // the LARGEST group a kernel is launched with; smaller launches use fewer
+#ifndef SURTR_DBG
 #define SURTR_DBG(...)
 #endif
 
 // Diagnostic build only (-DSURTR_STAMP): lane 0 accumulates s_memtime deltas per phase into a
 // global table that no product code reads.
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
 __device__ unsigned long long g_stamp[96];
 #ifdef SURTR_STAMP_SMALL
 #define STAMP_WHO (blockDim.x == 64 && gridDim.x > 1900)
@@ -75,25 +68,13 @@ __device__ unsigned long long g_stamp[96];
 #define SURTR_MAXF 127          // planes per cell (Voronoi cells have ~15, an ACH k-DOP up to 72)
 #define SURTR_DEAD (-3)          // comp of a tombstone
 // a value every lane holds equally, moved to a scalar register so that branches on it are scalar branches
-#ifdef SURTR_EMUL
-#define SURTR_UNIFORM(x) (x)
-#else
 #define SURTR_UNIFORM(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-#endif
 // vertices per bounding sphere of the spatially sorted copy (pre-pass A0); a wave of A1 takes LANES / SB undecided groups
-#ifdef SURTR_EMUL
-#define SURTR_SB 1u
-#else
 #ifndef SURTR_SB
 #define SURTR_SB 8u
 #endif
-#endif
 #ifndef SURTR_KEEPALL_V
-#ifdef SURTR_EMUL
-#define SURTR_KEEPALL_V 12u     // (emulation: small, so that the tests still run the culling on small meshes)
-#else
 #define SURTR_KEEPALL_V 1536u   // solids up to this many vertices skip the pre-pass culling (they fit the LDS topology whole)
-#endif
 #endif
 #define SURTR_NEVER 0xFFu       // fc of a vertex no plane clips
 #ifndef SURTR_WALK0
@@ -111,9 +92,11 @@ __device__ unsigned long long g_stamp[96];
 
 namespace surtr {
 
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (SURTR_LANES - 1u); }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> SURTR_LSH; }
+
 // Cross-lane moves without the LDS crossbar.  `__shfl*` compiles to ds_bpermute_b32 on gfx950 (an LDS-pipeline round trip per
 // call: six dependent ones per wave scan); the data-parallel-primitive modifiers move data between lanes inside the VALU.
-#ifndef SURTR_EMUL
 // lane i <- lane (i - N) of its row of 16 (row_shr:N), lanes without a source keep `old`
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_move(uint32_t old, uint32_t src)
@@ -124,29 +107,20 @@ __device__ __forceinline__ uint32_t dpp_move(uint32_t old, uint32_t src)
 __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)SURTR_UNIFORM(lane)); }
 __device__ __forceinline__ float lane_bcast(float v, uint32_t lane) { return __uint_as_float(lane_bcast(__float_as_uint(v), lane)); }
 __device__ __forceinline__ int lane_bcast(int v, uint32_t lane) { return (int)lane_bcast((uint32_t)v, lane); }
-#else
-__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t) { return v; }
-__device__ __forceinline__ float lane_bcast(float v, uint32_t) { return v; }
-__device__ __forceinline__ int lane_bcast(int v, uint32_t) { return v; }
-#endif
 
 
 // hist[f] += number of active lanes holding f: one LDS atomic per distinct value per wave instead of one per lane.
 __device__ __forceinline__ void wave_hist_add(uint32_t* hist, uint32_t f, bool active)
 {
-#ifdef SURTR_EMUL
-    if (active) hist[f] += 1u;
-#else
     unsigned long long todo = __ballot(active);
     while (todo)
     {
         const int leader = __builtin_ctzll(todo);
         const uint32_t f0 = lane_bcast(f, (uint32_t)leader);
         const unsigned long long same = __ballot(active && f == f0);
-        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&hist[f0], (uint32_t)__builtin_popcountll(same));
+        if ((int)lane_id() == leader) atomicAdd(&hist[f0], (uint32_t)__builtin_popcountll(same));
         todo &= ~same;
     }
-#endif
 }
 
 struct InLds
@@ -205,7 +179,7 @@ struct Shared
     uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;
     uint32_t misc[8];
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     unsigned long long ph[16];        // per-pair phase cycles (diagnostic build)
 #endif
 };
@@ -242,8 +216,6 @@ __device__ __forceinline__ int side_of(float s)
     return m > 0.f ? 1 : (m < 0.f ? -1 : 0);
 }
 
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (SURTR_LANES - 1u); }
-__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> SURTR_LSH; }
 // Size of the launched group and its wave count (kernels for small solids run one wave per task).
 __device__ __forceinline__ uint32_t group_size() { return blockDim.x; }
 __device__ __forceinline__ uint32_t group_waves() { return blockDim.x >> SURTR_LSH; }
@@ -252,14 +224,12 @@ __device__ __forceinline__ uint32_t group_waves() { return blockDim.x >> SURTR_L
 // (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six VALU operations per value.
 __device__ __forceinline__ uint2 wave_incl_scan2(uint2 v)
 {
-#ifndef SURTR_EMUL
     v.x += dpp_move<0x111, 0xF>(0u, v.x); v.y += dpp_move<0x111, 0xF>(0u, v.y);
     v.x += dpp_move<0x112, 0xF>(0u, v.x); v.y += dpp_move<0x112, 0xF>(0u, v.y);
     v.x += dpp_move<0x114, 0xF>(0u, v.x); v.y += dpp_move<0x114, 0xF>(0u, v.y);
     v.x += dpp_move<0x118, 0xF>(0u, v.x); v.y += dpp_move<0x118, 0xF>(0u, v.y);
     v.x += dpp_move<0x142, 0xA>(0u, v.x); v.y += dpp_move<0x142, 0xA>(0u, v.y);
     v.x += dpp_move<0x143, 0xC>(0u, v.x); v.y += dpp_move<0x143, 0xC>(0u, v.y);
-#endif
     return v;
 }
 
@@ -544,7 +514,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
         __syncthreads();
         nUnd = sh.misc[4];
         nWork = (nUnd + SURTR_LANES / SURTR_SB - 1u) / (SURTR_LANES / SURTR_SB);     // wave-loads of undecided groups
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         if (tid == 0 && V > 10000u) { atomicAdd(&g_stamp[45], (unsigned long long)nUnd); atomicAdd(&g_stamp[46], (unsigned long long)nsb); }
 #endif
     }
@@ -593,11 +563,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             bool all_done = true;
 #pragma unroll
             for (int g = 0; g < G; ++g) all_done = all_done && done4[g];
-#ifndef SURTR_EMUL
             if (__all(all_done)) break;
-#else
-            if (all_done) break;
-#endif
             const float4 pk = sh.planes[k];
             const float4 mk = sh.pmar[k];
 #pragma unroll
@@ -621,21 +587,10 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             const bool drop = valid4[g] && !keep && clear4[g];     // cannot be in-plane anywhere before fc (|s| > margin there)
             const bool need = valid4[g] && !keep && !clear4[g];
             wave_hist_add(sh.hist, f, drop);
-#ifdef SURTR_EMUL
-            const unsigned long long mk = keep ? 1ull : 0ull, mn = need ? 1ull : 0ull;
-#else
             const unsigned long long mk = __ballot(keep), mn = __ballot(need);
-#endif
             if (sorted)
             {
-                if (keep)
-                {
-#ifdef SURTR_EMUL
-                    bmask[v >> SURTR_LSH] |= 1ull << (v & (SURTR_LANES - 1u));
-#else
-                    atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-#endif
-                }
+                if (keep) atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
             }
             else if (l == 0) bmask[wb] = mk;
             if (keep) keep_deg(v, in.llen[v]);
@@ -652,7 +607,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     STAMP(0);
     // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
     const uint32_t nNeedy = sh.misc[3];
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     if (tid == 0 && V > 10000u) atomicAdd(&g_stamp[47], (unsigned long long)nNeedy);
 #endif
     for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += group_size())
@@ -703,11 +658,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
             drop = !keep;
             if (keep)
             {
-#ifdef SURTR_EMUL
-                bmask[v >> SURTR_LSH] |= 1ull << (v & (SURTR_LANES - 1u));
-#else
                 atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-#endif
                 keep_deg(v, deg);
             }
             else
@@ -901,11 +852,7 @@ __device__ inline void select_write(const uint8_t* arr, uint32_t val, uint32_t n
         uint32_t at = run + s2.x - (uint32_t)__builtin_popcount(m);
 #pragma unroll
         for (uint32_t q = 0; q < 4u; ++q) if (m & (1u << q)) list.set(at++, base + q);
-#ifdef SURTR_EMUL
-        run += s2.x;
-#else
         run += lane_bcast(s2.x, SURTR_LANES - 1u);
-#endif
     }
     __syncthreads();
 }
@@ -1185,7 +1132,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
             if (squeezed)
             {
                 COUNT(36);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
                 if (tid == 0) printf("overflow after squeeze: plane %u of %u, nS %u + M %u (capV %u), hUsed %u + 3M (capH %u), nLive %u\n", k, F, nS, M, T.capV, T.hUsed, T.capH, T.nLive);
 #endif
                 return SURTR_OVERFLOW;
@@ -1223,11 +1170,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
                 if (i < nC) { km = cutcnt.get(i); c.x = (km & 0x8000u) ? (km & 0x7FFFu) : (uint32_t)__builtin_popcount(km); }
                 const uint2 s2 = wave_incl_scan2(c);
                 const uint32_t base = run;
-#ifdef SURTR_EMUL
-                run += s2.x;
-#else
                 run += lane_bcast(s2.x, SURTR_LANES - 1u);
-#endif
                 if (i < nC && c.x)
                 {
                     const uint32_t v = clist.get(i);

@@ -10,13 +10,10 @@
 //   (scan)     ring offsets
 //   k_rings    one lane per vertex: walk again, write the ring with its rotation
 //   k_links    symmetric-link check (:253-260)
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#endif
 #include <cstring>
 
 #include "surtr_ctx.h"
+#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -120,22 +117,16 @@ extern "C" int surtr_neighbors_from_mesh_dev(surtr_ctx* ctx, uint32_t nv, uint32
     CK(hipMemcpyAsync(d_tris, tris, (size_t)nt * 12, hipMemcpyHostToDevice, st));
     CK(hipMemsetAsync(d_keys, 0xFF, (size_t)cap * 8, st)); CK(hipMemsetAsync(d_first, 0xFF, (size_t)nv * 4, st)); CK(hipMemsetAsync(d_err, 0, 4, st));
     CK(hipMemsetAsync(d_deg, 0, ((size_t)nv + 1) * 4, st));
-#ifndef SURTR_EMUL
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (kernel_ms) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-#endif
     const dim3 blk(256);
     hipLaunchKernelGGL(k_edges, dim3((3u * nt + 255) / 256), blk, 0, st, nv, nt, d_tris, d_keys, d_third, cap - 1u, d_first, d_err);
     hipLaunchKernelGGL(k_fans, dim3((nv + 255) / 256), blk, 0, st, nv, nt, d_tris, d_keys, d_third, cap - 1u, d_first, d_deg, d_off, d_nbr, 0u, d_err);
     uint32_t err = 0;
-#ifndef SURTR_EMUL
     size_t tmp_bytes = 0;
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, d_deg, d_off, (int)nv + 1, st);
     CK(hipMalloc(&d_tmp, tmp_bytes + 16));
     if (hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_deg, d_off, (int)nv + 1, st) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
-#else
-    { uint32_t run = 0; for (uint32_t v = 0; v <= nv; ++v) { d_off[v] = run; run += d_deg[v]; } }
-#endif
     // sum of the ring lengths = 3 T on a closed manifold; anything else was an error (checked before the rings are written)
     uint32_t total = 0;
     CK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st)); CK(hipMemcpyAsync(&total, d_off + nv, 4, hipMemcpyDeviceToHost, st));
@@ -145,9 +136,7 @@ extern "C" int surtr_neighbors_from_mesh_dev(surtr_ctx* ctx, uint32_t nv, uint32
     {
         hipLaunchKernelGGL(k_fans, dim3((nv + 255) / 256), blk, 0, st, nv, nt, d_tris, d_keys, d_third, cap - 1u, d_first, d_deg, d_off, d_nbr, 1u, d_err);
         hipLaunchKernelGGL(k_links, dim3((nv + 255) / 256), blk, 0, st, nv, d_off, d_nbr, d_err);
-#ifndef SURTR_EMUL
         if (kernel_ms) (void)hipEventRecord(e1, st);
-#endif
         CK(hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, st));
         CK(hipMemcpyAsync(nbr_off, d_off, ((size_t)nv + 1) * 4, hipMemcpyDeviceToHost, st));
         if (total) CK(hipMemcpyAsync(nbr, d_nbr, (size_t)total * 4, hipMemcpyDeviceToHost, st));
@@ -156,10 +145,8 @@ extern "C" int surtr_neighbors_from_mesh_dev(surtr_ctx* ctx, uint32_t nv, uint32
     if (kernel_ms)
     {
         *kernel_ms = -1.f;
-#ifndef SURTR_EMUL
         if (err == 0) (void)hipEventElapsedTime(kernel_ms, e0, e1);
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-#endif
     }
 #undef CK
     cleanup();

@@ -8,14 +8,11 @@
 //   surtr_pieces_from_event  the fragments of the last event become the pieces of the next one without leaving HBM
 //                            (recursive refracture, BASELINE configs[4])
 // All piece buffers come from a grow-only pool: in steady state (same or smaller pieces) no call allocates or frees.
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#endif
 #include <chrono>
 #include <cstring>
 
 #include "surtr_ctx.h"
+#include <hipcub/hipcub.hpp>      // (the emulation header brings its own two hipcub algorithms)
 
 namespace {
 
@@ -272,7 +269,6 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
     hipLaunchKernelGGL(k_piece_box, dim3(n), dim3(SURTR_WG), 0, st, n, S.vo, S.pos, S.box);
     hipLaunchKernelGGL(k_piece_keys, gridV, blk, 0, st, V, n, S.vo, S.pos, S.box, S.key, S.val);
     // stable sort of (piece, Morton code) -> piece-local vertex: per piece the host order std::sort gave pairs (code, vertex)
-#ifndef SURTR_EMUL
     int end_bit = 32;
     while (end_bit < 64 && (n >> (end_bit - 32)) != 0u) ++end_bit;
     size_t tmp_bytes = 0;
@@ -280,14 +276,6 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
     int rc = pool_reserve(ctx, &ctx->sort_tmp, ctx->c_sort_tmp, tmp_bytes + 16);
     if (rc) return rc;
     if (hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp, tmp_bytes, S.key, S.key2, S.val, S.perm, (int)V, 0, end_bit, st) != hipSuccess) return SURTR_E_HIP;
-#else
-    {
-        std::vector<uint32_t> order(V);
-        for (uint32_t v = 0; v < V; ++v) order[v] = v;
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return S.key[x] < S.key[y]; });
-        for (uint32_t i = 0; i < V; ++i) S.perm[i] = S.val[order[i]];
-    }
-#endif
     hipLaunchKernelGGL(k_piece_sorted, gridV, blk, 0, st, V, n, S.vo, S.pos, S.rad, S.perm, S.posr_s);
     if (NB) hipLaunchKernelGGL(k_piece_spheres, dim3((NB + 255) / 256), blk, 0, st, NB, n, S.vo, S.bo, S.posr_s, S.bsph);
     HIPCHK(hipGetLastError());

@@ -11,14 +11,11 @@
 // Only per-piece flags and labels (a few bytes per piece) cross the bus; the host turns them into the reference's bind sets
 // (first group of a compound stays, the others are appended in discovery order).  Pieces are numbered as in
 // surtr_regroup: the resident pieces the event skipped (its `outside` mask), ascending, then the event's fragments.
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#endif
 #include <cstring>
 #include <set>
 
 #include "surtr_ctx.h"
+#include <hipcub/hipcub.hpp>
 
 #define RG_MAXH 4096u       // half-edges of one Convex the face extraction handles
 
@@ -170,11 +167,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_rg_faces(uint32_t n_pieces, RgS
                 }
                 if (contain) hit = true;
             }
-#ifdef SURTR_EMUL
-        const bool any = hit;
-#else
         const bool any = __ballot(hit) != 0ull;
-#endif
         if (threadIdx.x == 0) out_flag[p] = any ? 0 : 1;
     }
 }
@@ -333,21 +326,12 @@ extern "C" int surtr_event_regroup(surtr_ctx* ctx, int partial, uint32_t n_spher
     {
         const dim3 blk(256), grid((nf + 255) / 256);
         hipLaunchKernelGGL(k_rg_keys, grid, blk, 0, st, nf, d_nodes.p, d_set.p, d_key.p, d_val.p);
-#ifndef SURTR_EMUL
         size_t tmp_bytes = 0;
         (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key.p, d_key2.p, d_val.p, d_order.p, (int)nf, 0, 64, st);
         Tmp<char> d_tmp;
         if (!d_tmp.alloc(tmp_bytes + 16)) return SURTR_E_HIP;
         if (hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_key.p, d_key2.p, d_val.p, d_order.p, (int)nf, 0, 64, st) != hipSuccess) return SURTR_E_HIP;
         HIPCHK(hipStreamSynchronize(st));
-#else
-        {
-            std::vector<uint32_t> ord(nf);
-            for (uint32_t f = 0; f < nf; ++f) ord[f] = f;
-            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return d_key.p[x] < d_key.p[y]; });
-            for (uint32_t f = 0; f < nf; ++f) { d_order.p[f] = d_val.p[ord[f]]; d_key2.p[f] = d_key.p[ord[f]]; }
-        }
-#endif
         hipLaunchKernelGGL(k_rg_pairs, grid, blk, 0, st, nf, d_order.p, d_key2.p, d_nodes.p, d_pts.p, d_edges.p, cap_edges, d_err + 1);
         uint32_t head[3] = {0, 0, 0};
         HIPCHK(hipMemcpyAsync(head, d_err, 12, hipMemcpyDeviceToHost, st));

@@ -1,9 +1,6 @@
 // surtr_ctx.h -- records shared by the translation units of libsurtr_hip.so: what the kernels of one event leave in HBM
 // (PairRec, FragRec, Arena), the resident pieces, the scratch pools, and the host-side context behind the C ABI.
 #pragma once
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#endif
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
@@ -207,11 +204,9 @@ struct surtr_ctx
     uint32_t* d_order = nullptr; uint32_t cap_order = 0;
     uint32_t* d_forder = nullptr;    // fragments by size class, 16 x cap_frags
     uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
-#ifndef SURTR_EMUL
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
     hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both
     hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr;
-#endif
     hipStream_t stream = nullptr;
     std::string err;
     // pieces
@@ -255,23 +250,14 @@ struct surtr_ctx
     void* d_blob = nullptr; size_t blob_cap = 0;
     // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
     bool profiling = false;
-#ifndef SURTR_EMUL
     hipEvent_t ev[32] = {};     // begin/end per kernel slot 0..15
-#endif
     bool ev_valid[16] = {};
 };
 
-#ifndef SURTR_EMUL
 #define PROF_BEGIN_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], strm); } } while (0)
 #define PROF_END_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], strm); ctx->ev_valid[i] = true; } } while (0)
 #define PROF_BEGIN(i) PROF_BEGIN_ON(i, st)
 #define PROF_END(i) PROF_END_ON(i, st)
-#else
-#define PROF_BEGIN(i) do { } while (0)
-#define PROF_END(i) do { } while (0)
-#define PROF_BEGIN_ON(i, strm) do { } while (0)
-#define PROF_END_ON(i, strm) do { } while (0)
-#endif
 
 #define HIPCHK(call)                                                                              \
     do {                                                                                          \

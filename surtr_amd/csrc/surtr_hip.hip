@@ -14,10 +14,6 @@
 //   k_faces         A9+A10  ExtractFaces + EarClipping of every Mesh           (Src/Poly.cpp:89-126, 764-913)
 //   k_out_scan / k_pack  coalesced write of the packed fragment blob
 // There is no CPU fallback: without a HIP device surtr_create fails with SURTR_E_NOGPU.
-#ifndef SURTR_EMUL
-#include <hip/hip_runtime.h>
-#endif
-
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -52,11 +48,11 @@ __host__ __device__ static inline bool fits_with_room(uint32_t n, uint32_t h, ui
 {
     return n + capV / 5u <= capV && h + capH / 6u <= capH;
 }
-#ifdef SURTR_EMUL
-typedef LdsTopoT<64, 512> LdsTopoSmall;                 // (emulation: small enough to exercise the fallback too)
-#else
-typedef LdsTopoT<256, 2048> LdsTopoSmall;               // Convex solids: one wave per task, many tasks per CU
+#ifndef SURTR_SMALL_LV
+#define SURTR_SMALL_LV 256
+#define SURTR_SMALL_LH 2048
 #endif
+typedef LdsTopoT<SURTR_SMALL_LV, SURTR_SMALL_LH> LdsTopoSmall;      // Convex solids: one wave per task, many tasks per CU
 
 // Work arrays of a Topo in LDS.  Convex solids have a few dozen vertices: with positions and work lists next to the
 // topology no phase of their plane loop waits for HBM.  Used when the input solid has at most N vertices.
@@ -136,12 +132,12 @@ __device__ __attribute__((always_inline)) static inline int clip_any(const Solid
             bmask = (unsigned long long*)bblk - nbV;
             capEmit = LT::kLH - nbV * 8u;
         }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
         if (LW::kN != 0 && in.nv <= LW::kN && in.nv <= SURTR_KEEPALL_V) rc = load_whole(in, F, T, sh);      // a Convex: no culling, no masks
         else rc = prepass(in, F, T, sh, bmask, bblk, capEmit, S.gmask, S.gblk);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
         if (rc == 0)
@@ -150,7 +146,7 @@ __device__ __attribute__((always_inline)) static inline int clip_any(const Solid
             rc = clip_planes<InLds, LW::kN == 0>(T, F, sh, in, S.gmask, SqueezeTmp{S.t_pos, S.t_loff, S.t_llen, S.t_comp, S.t_ring});
         }
         __syncthreads();
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long q2 = __builtin_readcyclecounter();
         if (rc == 0)
         {
@@ -536,7 +532,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         PairRec rec;
         memset(&rec, 0, sizeof(rec));
-#if defined(SURTR_STAMP_SMALL) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP_SMALL
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
 #endif
         bool skip = outside != nullptr && outside[piece] != 0;
@@ -608,7 +604,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                 porder[(size_t)cls * n_pairs + atomicAdd(&A.cursors[48u + cls], 1u)] = p;
             }
         }
-#if defined(SURTR_STAMP_SMALL) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP_SMALL
         if (tid == 0) for (int q = 0; q < 16; ++q) if (sh.ph[q]) atomicAdd(&g_stamp[q], sh.ph[q]);
 #endif
     }
@@ -619,12 +615,8 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 // several workgroups share a CU and hide each other's gather latency.  The reduced solid goes to HBM as an
 // "image" in the layout of the LDS topology; k_clip_pairs loads it with plain copies.  Pairs this kernel leaves
 // alone (small solids, image arena full) are pre-passed by k_clip_pairs itself.
-#ifdef SURTR_EMUL
-#define SURTR_PREP_MINV 48u
-#else
 #ifndef SURTR_PREP_MINV
 #define SURTR_PREP_MINV 2048u      // smaller meshes are pre-passed by k_clip_pairs itself (measured on BASELINE configs[4])
-#endif
 #endif
 #define SURTR_PREP_NB 1024u         // 64-vertex blocks whose masks fit this kernel's LDS (65536 vertices)
 #ifndef SURTR_PREP_WAVES
@@ -652,7 +644,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_SB + 2) * 4);
     unsigned long long* gmask = (unsigned long long*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
     unsigned long long wg_work = 0;
 #endif
@@ -688,7 +680,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             }
             continue;
         }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
 #endif
         STAMP_DECL;
@@ -759,11 +751,11 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
             if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; wg_work += d; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 7) bkt = 7; atomicAdd(&g_stamp[62 + bkt], 1ull); }
 #endif
     }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp[56], d); atomicMax(&g_stamp[57], d); atomicAdd(&g_stamp[58], 1ull); atomicAdd(&g_stamp[59], wg_work); atomicMax(&g_stamp[60], wg_work); }
 #endif
 }
@@ -804,7 +796,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
 {
     const uint32_t tid = threadIdx.x;
     Scratch S = carve(pool, wg);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
 #endif
     // classes of the half table this launch takes: 6..1 (k_clip_pairs_half), its retry list (cls_hi < 0), or none
@@ -838,7 +830,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         PairRec rec = pairs[p];
         if (rec.cv_n == 0 || rec.status != 0) continue;       // empty Convex: the Mesh is not clipped (:1467-1468)
         if (rec.img_fmt == IMG_EMPTY) continue;               // the pre-pass kernel found nothing left of the Mesh
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
 #endif
@@ -883,13 +875,13 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
         if (tid == 0) pairs[p] = rec;
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[(cls_hi == 15 ? 51 : 21) + bkt], 1ull);
             if (d > (1ull << 21)) printf("slow pair %u: %llu cycles, n %u F %u | cls %llu patch %llu fin/serial %llu tail %llu scan %llu sweep %llu create %llu jump %llu walk0 %llu pred %llu walk1 %llu\n", p, d, rec.img_n, F,
                 sh.ph[4], sh.ph[5], sh.ph[6], sh.ph[7], sh.ph[8], sh.ph[9], sh.ph[10], sh.ph[11], sh.ph[12], sh.ph[13], sh.ph[14]); }
 #endif
     }
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
     if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; const int o = cls_hi == 15 ? 48 : 16; atomicAdd(&g_stamp[o], d); atomicMax(&g_stamp[o + 1], d); atomicAdd(&g_stamp[o + 2], 1ull); }
 #endif
 }
@@ -1011,7 +1003,6 @@ __device__ static A wg_argmax(A mine, A* slots /* shared, SURTR_NWAVE */)
 {
     // wave reduce ("larger value, then smaller index" is associative and commutative): the scan pattern of wave_incl_scan2
     // with that operator leaves the result in the last lane; lanes without a source receive the invalid index
-#ifndef SURTR_EMUL
     auto step = [&](auto mv) {
         A o = mv(mine);
         if (o.i != 0xFFFFFFFFu && (mine.i == 0xFFFFFFFFu || o.v > mine.v || (o.v == mine.v && o.i < mine.i))) mine = o;
@@ -1042,7 +1033,6 @@ __device__ static A wg_argmax(A mine, A* slots /* shared, SURTR_NWAVE */)
     step(mover(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{}));
     step(mover(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{}));
     step(mover(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{}));
-#endif
     __syncthreads();
     if (lane_id() == SURTR_LANES - 1u) slots[wave_id()] = mine;
     __syncthreads();
@@ -1087,7 +1077,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         FragRec fr = frags[f];
         const float* mp = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t n = fr.mv_n;
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long r0 = __builtin_readcyclecounter();
 #endif
         // ---- BuildFirstHull (Src/VMACH.cpp:1036-1085) with limit min(n,4) = 4 ----
@@ -1152,7 +1142,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long r1 = __builtin_readcyclecounter();
 #endif
         // ---- Kdop::Calc(Polyhedron) (Src/Kdop.cpp:92-115): first minimum / first maximum of n.v ----
@@ -1177,7 +1167,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         if (tid == 0) { const unsigned long long r2 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[94], r1 - r0); atomicAdd(&g_stamp[95], r2 - r1); }
 #endif
         SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1283,7 +1273,7 @@ __device__ static uint32_t ear_clip_face(const float* pos, const int32_t* loop, 
     return at + 3;
 }
 
-#ifndef SURTR_EMUL
+#if SURTR_LANES == 64
 // Poly::EarClipping for one face of 5..64 vertices on one wave: lane i holds vertex i (position, prev/next
 // link, reflex flag) in registers; the sequential ear loop (:868-906) runs wave-uniformly, and the scan of the
 // reflex list (:837-856, an "any reflex vertex inside the candidate ear") is one ballot.  Same triangles, same
@@ -1415,7 +1405,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         FragRec fr = frags[f];
         const uint32_t n = fr.mv_n, H = fr.mh_n;
         STAMP_DECL;
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         const unsigned long long frag_t0 = __builtin_readcyclecounter();
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
 #endif
@@ -1698,7 +1688,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 fcnt[fi] = at;
             }
         }
-#ifndef SURTR_EMUL
+#if SURTR_LANES == 64
         for (uint32_t fi = wave_id(); fi < (fan ? 0u : nfaces); fi += group_waves())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
@@ -1712,12 +1702,12 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         for (uint32_t fi = tid; fi < (fan ? 0u : nfaces); fi += group_size())
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
-#ifndef SURTR_EMUL
+#if SURTR_LANES == 64
             if (len >= 5u && len <= 64u) continue;
 #endif
             uint32_t* out = tri + 3u * (size_t)lo;
             fcnt[fi] = (len >= 3u) ? ear_clip_face(pos, loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out) : 0u;
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
             if (len > 64u) { atomicAdd(&g_stamp[66], 1ull); atomicAdd(&g_stamp[67], (unsigned long long)len); }
 #endif
         }
@@ -1749,7 +1739,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         }
         if (tid == 0) { frags[f].idx_off = ioff; frags[f].idx_n = nidx; }     // field-wise: k_refit runs beside this kernel
         STAMP(65);
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
         if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - frag_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 14 ? 0 : bkt - 14; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[70 + bkt], 1ull); const unsigned long long old = atomicMax(&g_stamp[68], d); if (d > old) { g_stamp[69] = n; g_stamp[61 + 16] = H; g_stamp[62 + 16] = nfaces; for (int q = 0; q < 6; ++q) g_stamp[32 + q] = sh.ph[(60 + q) & 15]; } }
 #endif
     }
@@ -1984,13 +1974,11 @@ int surtr_create(int device, surtr_ctx** out)
     }
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
     if (hipMalloc((void**)&ctx->arena.cursors, 512) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-#ifndef SURTR_EMUL
     if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-#endif
     *out = ctx;
     return SURTR_OK;
 }
@@ -2006,14 +1994,12 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->d_pair_order); free_dev(ctx->d_face_group);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
-#ifndef SURTR_EMUL
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_half) (void)hipEventDestroy(ctx->ev_half);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     for (int i = 0; i < 32; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
-#endif
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
     free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_frag_status); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
@@ -2340,14 +2326,10 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
-#ifndef SURTR_EMUL
     hipStream_t st2 = ctx->stream2, st3 = ctx->stream3;
     HIPCHK(hipEventRecord(ctx->ev_prep, st));
     HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
     HIPCHK(hipStreamWaitEvent(st3, ctx->ev_prep, 0));
-#else
-    hipStream_t st2 = st, st3 = st;
-#endif
     PROF_BEGIN(8);
     if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
@@ -2363,10 +2345,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         hipLaunchKernelGGL(k_clip_pairs_half, dim3(n_wg_half), dim3(SURTR_WGS), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool_half, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)32 * ctx->cap_order);
     PROF_END_ON(9, st3);
-#ifndef SURTR_EMUL
     HIPCHK(hipEventRecord(ctx->ev_half, st3));
     HIPCHK(hipStreamWaitEvent(st2, ctx->ev_half, 0));
-#endif
     // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
     // (it reuses the scratch slots of the first launch)
     PROF_BEGIN_ON(10, st2);
@@ -2374,10 +2354,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
     PROF_END_ON(10, st2);
-#ifndef SURTR_EMUL
     HIPCHK(hipEventRecord(ctx->ev_big, st2));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
-#endif
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
                        ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list, ctx->d_forder);
@@ -2385,14 +2363,12 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // refit (Convex) and faces (Mesh) of the fragments are independent: side by side on the two streams
     const bool both = (flags & SURTR_EVT_REFIT) && (flags & SURTR_EVT_RENDER);
     hipStream_t st_refit = st;
-#ifndef SURTR_EMUL
     if (both)
     {
         HIPCHK(hipEventRecord(ctx->ev_prep, st));
         HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
         st_refit = st2;
     }
-#endif
     if (flags & SURTR_EVT_REFIT)
     {
         PROF_BEGIN_ON(2, st_refit);
@@ -2407,13 +2383,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->d_frag_status);
         PROF_END(3);
     }
-#ifndef SURTR_EMUL
     if (both)
     {
         HIPCHK(hipEventRecord(ctx->ev_big, st2));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
     }
-#endif
     PROF_BEGIN(4);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     PROF_END(4);
@@ -2751,7 +2725,7 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
     return SURTR_OK;
 }
 
-#if defined(SURTR_STAMP) && !defined(SURTR_EMUL)
+#ifdef SURTR_STAMP
 int surtr_debug_stamps(unsigned long long out[96], int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 96) != hipSuccess) return SURTR_E_HIP;
@@ -2763,11 +2737,9 @@ int surtr_debug_stamps(unsigned long long out[96], int reset)
 int surtr_set_profiling(surtr_ctx* ctx, int on)
 {
     if (!ctx) return SURTR_E_INVALID;
-#ifndef SURTR_EMUL
     (void)hipSetDevice(ctx->device);
     if (on && !ctx->ev[0])
         for (int i = 0; i < 32; ++i) HIPCHK(hipEventCreate(&ctx->ev[i]));
-#endif
     ctx->profiling = on != 0;
     return SURTR_OK;
 }
@@ -2776,12 +2748,10 @@ int surtr_kernel_times(surtr_ctx* ctx, float ms[16])
 {
     if (!ctx || !ms) return SURTR_E_INVALID;
     for (int i = 0; i < 16; ++i) ms[i] = -1.f;
-#ifndef SURTR_EMUL
     (void)hipSetDevice(ctx->device);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 16; ++i)
         if (ctx->ev_valid[i]) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ms[i] = t; }
-#endif
     return SURTR_OK;
 }
 

@@ -6,6 +6,20 @@
 // the product against the oracle without a GPU; it cannot show races and is
 // never loaded by surtr_amd (engine.py only opens libsurtr_hip.so).
 #pragma once
+// geometry and capacities of the emulation: one lane per wave, one thread per workgroup; small thresholds so that small test
+// meshes still go through the culling, the separate pre-pass kernel and the global-scratch fallback of the one-wave kernels
+#define SURTR_LANES 1
+#define SURTR_LSH 0
+#define SURTR_WG 1
+#define SURTR_SB 1u
+#ifndef SURTR_KEEPALL_V
+#define SURTR_KEEPALL_V 12u
+#endif
+#define SURTR_PREP_MINV 48u
+#define SURTR_SMALL_LV 64
+#define SURTR_SMALL_LH 512
+#include <cstdio>
+#define SURTR_DBG(...) fprintf(stderr, __VA_ARGS__)
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -36,8 +50,20 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
 
+// one lane per wave: the cross-lane primitives degenerate to the identity
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline bool __all(bool p) { return p; }
+template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int __builtin_amdgcn_readlane(int v, int) { return v; }
+static inline int __builtin_amdgcn_update_dpp(int old, int, int, int, int, bool) { return old; }      // lane 0 never has a source lane
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
 typedef int hipError_t;
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 enum { hipSuccess = 0 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
 struct hipDeviceProp_t { int multiProcessorCount; };
@@ -53,6 +79,47 @@ static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+// streams and events: everything runs in program order
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+
+// the two hipCUB device algorithms the host code calls (stable LSD radix sort of pairs by key bits; exclusive sum)
+#include <algorithm>
+#include <vector>
+namespace hipcub {
+struct DeviceRadixSort
+{
+    template <class K, class V>
+    static hipError_t SortPairs(void* tmp, size_t& tmp_bytes, const K* kin, K* kout, const V* vin, V* vout, int n, int begin_bit, int end_bit, hipStream_t)
+    {
+        if (!tmp) { tmp_bytes = 16; return hipSuccess; }
+        std::vector<int> ord(n);
+        for (int i = 0; i < n; ++i) ord[i] = i;
+        const K mask = end_bit >= (int)(8 * sizeof(K)) ? ~(K)0 : (((K)1 << end_bit) - 1);
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return ((kin[a] & mask) >> begin_bit) < ((kin[b] & mask) >> begin_bit); });
+        for (int i = 0; i < n; ++i) { kout[i] = kin[ord[i]]; vout[i] = vin[ord[i]]; }
+        return hipSuccess;
+    }
+};
+struct DeviceScan
+{
+    template <class T>
+    static hipError_t ExclusiveSum(void* tmp, size_t& tmp_bytes, const T* in, T* out, int n, hipStream_t)
+    {
+        if (!tmp) { tmp_bytes = 16; return hipSuccess; }
+        T run = 0;
+        for (int i = 0; i < n; ++i) { const T v = in[i]; out[i] = run; run += v; }
+        return hipSuccess;
+    }
+};
+} // namespace hipcub
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                         \
     do {                                                                                   \
