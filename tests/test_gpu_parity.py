@@ -523,3 +523,47 @@ def test_cpp_rccl_harness_single_rank(oracle):
     planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
     ref = oracle.event([sc["mesh"]], [ach], sc["face_off"], planes, threads=8)
     assert out["ranks"] == 1 and out["fragments"] == ref["frag_ids"].shape[0] and out["per_rank"] == [ref["frag_ids"].shape[0]]
+
+
+def test_wide_global_scratch_variant_gpu(gpu_engine, oracle):
+    """A band that outgrows even the double-size LDS topology (a 350 000-vertex torus cut by 8 large cells): the pair is clipped
+    by the same templated code on global scratch with 32-bit indices (Topo<InGlobal>).  Round 1 had this on the emulation only."""
+    v, t = meshgen.bumpy_torus(700, 500)
+    sc = scenes.make_scene(v, t, 8)
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+    c = eng.fracture_event(0, 8, flags=3)
+    got = eng.download()
+    qs = eng.queue_stats()
+    eng.close()
+    assert c.status == 0 and qs[16 + 15] > 0, "no pair took the global-scratch variant: %s" % qs[16:32].tolist()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, threads=8)
+    assert_event_equal(got, ref)
+
+
+def test_fracture_pattern_around_an_impact_point(gpu_engine, oracle):
+    """Surtr::GenerateFracturePattern + DoFracture's placement (Src/Surtr.cpp:2072-2096, 1887-1896): cells dense around the
+    pattern origin (exponential seed distances), the pattern scaled by 2 x MaxAxisScale and moved to an impact point on the
+    surface; cells built on the device."""
+    sc = scenes.blob_scene(8)
+    seeds = scenes.pattern_seeds(128, 0.05)
+    v = sc["mesh"]["pos"]
+    lo, hi = v.min(0), v.max(0)
+    max_axis = np.float32(max(float(hi[a]) - float(lo[a]) for a in range(3)))
+    scale = np.full(3, np.float32(2.0) * max_axis, np.float32)
+    impact = v[np.argmax(v[:, 0])].astype(np.float32)
+    eng = gpu_engine.Engine(0)
+    eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+    eng.build_cells(seeds)
+    cells = eng.download_cells()
+    ref_cells = gpu_engine.voronoi_cells(seeds)
+    assert np.array_equal(cells["face_gen"], ref_cells["face_gen"]) and np.array_equal(cells["verts"], ref_cells["verts"].reshape(-1, 3))
+    eng.place_cells(scale, impact)
+    c = eng.fracture_event(0, 128, flags=3)
+    got = eng.download()
+    eng.close()
+    planes = oracle.place_cells(cells["v012"], scale, impact)
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], cells["cell_face_off"], planes, threads=8)
+    assert c.status == 0 and c.n_frag > 20
+    assert_event_equal(got, ref)
