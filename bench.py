@@ -105,7 +105,11 @@ def main():
     from surtr_amd import engine, scenes, multigpu
 
     flags = engine.EVT_REFIT | engine.EVT_RENDER
-    base = scenes.torus_scene(args.cells)          # seed 46354: BASELINE configs[3]
+    from surtr_amd import meshgen
+    boot = engine.Engine(local_rank)
+    base = scenes.mesh_scene(*meshgen.bumpy_torus(), eng=boot)      # BASELINE configs[3]'s piece; rings built on the device
+    base["n_cells"] = args.cells
+    boot.close()
 
     def setup(mode):
         """Engine + inputs of this rank for one scaling mode; returns the step closure and what it gathers into."""

@@ -56,6 +56,15 @@ def box_solid(extent, center, factor=2.0):
     return {"pos": pos.astype(np.float32), "off": np.arange(0, 25, 3, dtype=np.uint32), "nbr": nb.reshape(-1)}
 
 
+def mesh_scene(verts, tris, eng=None):
+    """The piece alone (no pattern): neighbour rings (on the device when an Engine is given), bounding box, the 2x box Convex."""
+    mesh = eng.neighbors_from_mesh(verts, tris)[0] if eng is not None else engine.neighbors_from_mesh(verts, tris)
+    lo, hi = verts.min(0), verts.max(0)
+    extent = (hi - lo).astype(np.float32)
+    center = ((hi.astype(np.float64) + lo.astype(np.float64)) / 2.0).astype(np.float32)
+    return {"mesh": mesh, "convex": box_solid(extent, center), "tris": tris, "scale": extent, "translate": center}
+
+
 def make_scene(verts, tris, n_cells, seeds=None, eng=None):
     """eng: an Engine -> the Voronoi cells are built on the device (surtr_build_cells, which also leaves them installed as
     that engine's pattern); None -> the host builder (CPU tier, no GPU needed).  Same cells either way."""
