@@ -1972,13 +1972,14 @@ int surtr_create(int device, surtr_ctx** out)
             ctx->max_wg_prep = (uint32_t)prop.multiProcessorCount * prep_per_cu;
         }
     }
-    if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-    if (hipMalloc((void**)&ctx->arena.cursors, 512) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
-    if (hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+    // (surtr_destroy releases whatever was created so far: no leak on a failure half-way)
+    if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess ||
+        hipMalloc((void**)&ctx->arena.cursors, 512) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { delete ctx; return SURTR_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { surtr_destroy(ctx); return SURTR_E_HIP; }
     *out = ctx;
     return SURTR_OK;
 }

@@ -567,3 +567,18 @@ def test_fracture_pattern_around_an_impact_point(gpu_engine, oracle):
     ref = oracle.event([sc["mesh"]], [sc["convex"]], cells["cell_face_off"], planes, threads=8)
     assert c.status == 0 and c.n_frag > 20
     assert_event_equal(got, ref)
+
+
+import test_edge_cases as _ec
+
+
+@pytest.mark.parametrize("case", _ec.CASES, ids=lambda f: f.__name__)
+def test_edge_cases_gpu(gpu_engine, oracle, case):
+    import inspect
+    case(gpu_engine, oracle) if len(inspect.signature(case).parameters) == 2 else case(gpu_engine)
+
+
+def test_graft_entry_smoke():
+    """__graft_entry__.smoke(): the one small event the driver runs before the bench."""
+    import __graft_entry__
+    __graft_entry__.smoke()
