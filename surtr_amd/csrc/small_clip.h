@@ -1,0 +1,239 @@
+// small_clip.h -- Poly::ClipPolyhedron (Src/Poly.cpp:265-500) for a SMALL solid on ONE wave, regular planes only.
+//
+// The general clipper of clip_core.h pays ~25 000 cycles per plane whatever the size of the solid (its lists, scans and
+// look-ahead are built for bands of thousands of vertices).  The Convex solids of the path -- the piece's hull clipped by a
+// cell (k_clip_convex), a fragment's Convex clipped by its k-DOP slabs (k_refit) -- have a few dozen vertices and almost
+// always clip "regularly": no vertex in a plane, no ring that lists a neighbour twice, every cap a simple loop.  For those this
+// file follows the reference plane by plane, compaction included (:464-495), with the whole solid in LDS and no list at all:
+//   classify (:307-318)            one lane per vertex; any in-plane vertex -> not regular
+//   new vertices (:333-357)        numbered in (clipped vertex, slot) order by one prefix sum over the vertices
+//   relink (:367-431)              every new vertex walks its face through clipped vertices to the next new vertex: its ring
+//                                  is [predecessor, successor, kept end]; a walk that does not end on a new vertex, or two walks
+//                                  ending on the same one -> not regular
+//   compaction (:464-495)          kept vertices in order, then the new ones, rings renumbered, into the other LDS buffer
+// "Not regular" (or too large) returns SC_FALLBACK before anything is published: the caller runs the general clipper on the
+// same input, which handles in-plane vertices, doubled neighbours, two-neighbour collapses and the reference's error cases.
+// Results are those of the general clipper bit for bit (same arithmetic: plane_dist / side_of / the intersection formula).
+#pragma once
+#include "clip_core.h"
+
+#define SC_V 256u            // vertices of the solid at any time
+#define SC_H 1024u           // ring entries
+#define SC_FALLBACK 101      // internal: not regular / does not fit -> general clipper
+
+namespace surtr {
+
+struct ScSolid
+{
+    float pos[3 * SC_V];
+    uint16_t loff[SC_V]; uint8_t llen[SC_V];
+    uint16_t ring[SC_H];
+};
+
+struct ScLds
+{
+    ScSolid buf[2];
+    int8_t c[SC_V];                       // comp of the plane in progress
+    uint16_t km[SC_V];                    // clipped vertex: bit j = ring slot j holds a kept neighbour
+    uint16_t base[SC_V];                  // clipped vertex: number of its first new vertex
+    uint16_t newidx[SC_V];                // kept vertex: its index after the compaction
+    uint16_t noff[SC_V];                  // kept vertex: its ring offset after the compaction
+    uint16_t succ[SC_V], pred[SC_V];      // per new vertex
+    uint32_t nv[2], flag;
+};
+
+// slot of `who` in the ring of v (its length when absent)
+__device__ __forceinline__ uint32_t sc_slot(const ScSolid& S, uint32_t v, uint32_t who)
+{
+    const uint16_t* r = S.ring + S.loff[v]; const uint32_t n = S.llen[v];
+    uint32_t q = 0;
+    while (q < n && (uint32_t)r[q] != who) ++q;
+    return q;
+}
+
+// Clips `in` by sh.planes[0..F).  0: done, the result is L.buf[*which] with L.nv[*which] vertices (0 = empty);
+// SC_FALLBACK: use the general clipper.  One wave; every lane must call it.
+__device__ inline int small_clip(const SolidIn in, const uint32_t F, const Shared& sh, ScLds& L, uint32_t* which)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t V = in.nv;
+    if (V == 0 || V > SC_V) return SC_FALLBACK;
+    const uint32_t hbase = in.loff[0], H = in.loff[V - 1u] + in.llen[V - 1u] - hbase;
+    if (H > SC_H) return SC_FALLBACK;
+    bool odd = false;
+    for (uint32_t v = lane; v < V; v += SURTR_LANES)
+    {
+        ScSolid& S = L.buf[0];
+        S.pos[3 * v] = in.pos[3 * v]; S.pos[3 * v + 1] = in.pos[3 * v + 1]; S.pos[3 * v + 2] = in.pos[3 * v + 2];
+        const uint32_t lo = in.loff[v] - hbase, deg = in.llen[v];
+        if (deg > 15u || deg < 3u) odd = true;
+        S.loff[v] = (uint16_t)lo; S.llen[v] = (uint8_t)(deg > 15u ? 15u : deg);
+        const int32_t* r = in.nbr + in.loff[v];
+        for (uint32_t j = 0; j < deg && lo + j < SC_H; ++j) S.ring[lo + j] = (uint16_t)r[j];
+    }
+    if (__ballot(odd) != 0ull) return SC_FALLBACK;
+    __syncthreads();
+    uint32_t cur = 0, nv = V;
+    for (uint32_t k = 0; k < F && nv != 0u; ++k)
+    {
+        const float4 pl = sh.planes[k];
+        ScSolid& S = L.buf[cur]; ScSolid& N = L.buf[cur ^ 1u];
+        // ---- classify ----
+        bool zero = false, cut = false, keep = false;
+        for (uint32_t v = lane; v < nv; v += SURTR_LANES)
+        {
+            const int c = side_of(plane_dist(pl, S.pos[3 * v], S.pos[3 * v + 1], S.pos[3 * v + 2]));
+            L.c[v] = (int8_t)c;
+            zero = zero || c == 0; cut = cut || c < 0; keep = keep || c > 0;
+        }
+        if (__ballot(zero) != 0ull) return SC_FALLBACK;
+        if (__ballot(cut) == 0ull) continue;                         // "above": nothing to do (the solid has >= 4 vertices)
+        if (__ballot(keep) == 0ull) { nv = 0; break; }               // "below": everything goes (:322-327)
+        __syncthreads();
+        // ---- new vertices in (clipped vertex, slot) order; kept vertices' new indices and ring offsets ----
+        uint32_t carryM = 0, carryK = 0, carryH = 0;
+        bool dup = false;
+        for (uint32_t v0 = 0; v0 < nv; v0 += SURTR_LANES)
+        {
+            const uint32_t v = v0 + lane;
+            uint32_t mask = 0, isKept = 0, deg = 0;
+            if (v < nv)
+            {
+                deg = S.llen[v];
+                const uint16_t* r = S.ring + S.loff[v];
+                // a ring that lists a vertex twice (slivers; a cap of two vertices) makes the reference's first-occurrence
+                // patches and walks order dependent: the general clipper reproduces that, this one does not try
+                for (uint32_t j = 1; j < deg; ++j) for (uint32_t jj = 0; jj < j; ++jj) if (r[jj] == r[j]) dup = true;
+                if (L.c[v] > 0) isKept = 1u;
+                else
+                    for (uint32_t j = 0; j < deg; ++j) if (L.c[r[j]] > 0) mask |= 1u << j;
+            }
+            const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
+            // one scan for the three running sums: new vertices | kept vertices << 16, kept ring entries
+            const uint2 inc = wave_incl_scan2(make_uint2(cnt | (isKept << 16), isKept ? deg : 0u));
+            if (v < nv)
+            {
+                L.km[v] = (uint16_t)mask;
+                L.base[v] = (uint16_t)(carryM + (inc.x & 0xFFFFu) - cnt);
+                L.newidx[v] = (uint16_t)(carryK + (inc.x >> 16) - isKept);
+                L.noff[v] = (uint16_t)(carryH + inc.y - (isKept ? deg : 0u));
+            }
+            const uint32_t tx = lane_bcast(inc.x, SURTR_LANES - 1u), ty = lane_bcast(inc.y, SURTR_LANES - 1u);
+            carryM += tx & 0xFFFFu; carryK += tx >> 16; carryH += ty;
+        }
+        if (__ballot(dup) != 0ull) return SC_FALLBACK;
+        const uint32_t M = carryM, nKeep = carryK, HK = carryH;
+        if (nKeep + M > SC_V || HK + 3u * M > SC_H) return SC_FALLBACK;
+        if (nKeep + M < 4u) { nv = 0; break; }                        // (:497-499)
+        for (uint32_t t = lane; t < M; t += SURTR_LANES) L.pred[t] = 0xFFFFu;
+        __syncthreads();
+        // ---- relink: successor of every new vertex along the face through its clipped end ----
+        bool bad = false;
+        for (uint32_t v = lane; v < nv; v += SURTR_LANES)
+        {
+            uint32_t mask = L.c[v] < 0 ? L.km[v] : 0u;
+            uint32_t t = L.base[v];
+            for (; mask; mask &= mask - 1u, ++t)
+            {
+                // new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j, and so on
+                uint32_t cv = v, slot = (uint32_t)__builtin_ctz(mask), steps = 0, end = 0xFFFFu;
+                while (steps++ <= nv)
+                {
+                    const uint32_t len = S.llen[cv];
+                    const uint32_t p = slot == 0u ? len - 1u : slot - 1u;
+                    const uint32_t e = S.ring[S.loff[cv] + p];
+                    if (L.c[e] > 0) { end = L.base[cv] + (uint32_t)__builtin_popcount(L.km[cv] & ((1u << p) - 1u)); break; }
+                    const uint32_t q = sc_slot(S, e, cv);             // the walk arrives at clipped e from cv
+                    if (q >= S.llen[e]) break;
+                    cv = e; slot = q;
+                }
+                if (end == 0xFFFFu || end == t) { bad = true; continue; }
+                L.succ[t] = (uint16_t)end;
+                L.pred[end] = (uint16_t)t;                             // two walks ending on `end`: one of them does not find itself below
+            }
+        }
+        if (__ballot(bad) != 0ull) return SC_FALLBACK;
+        __syncthreads();
+        for (uint32_t t = lane; t < M; t += SURTR_LANES) if (L.pred[t] == 0xFFFFu || L.pred[L.succ[t]] != t) bad = true;
+        if (__ballot(bad) != 0ull) return SC_FALLBACK;
+        // ---- the solid after this plane, compacted (:464-495): kept vertices in order, then the new ones ----
+        for (uint32_t v = lane; v < nv; v += SURTR_LANES)
+        {
+            const uint16_t* r = S.ring + S.loff[v];
+            const uint32_t deg = S.llen[v];
+            if (L.c[v] > 0)
+            {
+                const uint32_t id = L.newidx[v], lo = L.noff[v];
+                N.pos[3 * id] = S.pos[3 * v]; N.pos[3 * id + 1] = S.pos[3 * v + 1]; N.pos[3 * id + 2] = S.pos[3 * v + 2];
+                N.loff[id] = (uint16_t)lo; N.llen[id] = (uint8_t)deg;
+                for (uint32_t j = 0; j < deg; ++j)
+                {
+                    const uint32_t e = r[j];
+                    uint32_t to;
+                    if (L.c[e] > 0) to = L.newidx[e];
+                    else
+                    {
+                        // the link to a clipped neighbour now holds the new vertex on that edge (:350-354)
+                        const uint32_t q = sc_slot(S, e, v);
+                        to = nKeep + L.base[e] + (uint32_t)__builtin_popcount(L.km[e] & ((1u << q) - 1u));
+                    }
+                    N.ring[lo + j] = (uint16_t)to;
+                }
+            }
+            else
+            {
+                const float ax = S.pos[3 * v], ay = S.pos[3 * v + 1], az = S.pos[3 * v + 2];
+                const float sa = plane_dist(pl, ax, ay, az);
+                uint32_t t = L.base[v];
+                for (uint32_t mask = L.km[v]; mask; mask &= mask - 1u, ++t)
+                {
+                    const uint32_t u = r[__builtin_ctz(mask)];
+                    const float bx = S.pos[3 * u], by = S.pos[3 * u + 1], bz = S.pos[3 * u + 2];
+                    const float sb = plane_dist(pl, bx, by, bz);
+                    // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
+                    const float inv = 1.f / (sb - sa);
+                    const uint32_t id = nKeep + t, lo = HK + 3u * t;
+                    N.pos[3 * id] = (ax * sb - bx * sa) * inv;
+                    N.pos[3 * id + 1] = (ay * sb - by * sa) * inv;
+                    N.pos[3 * id + 2] = (az * sb - bz * sa) * inv;
+                    N.loff[id] = (uint16_t)lo; N.llen[id] = 3;
+                    N.ring[lo] = (uint16_t)(nKeep + L.pred[t]); N.ring[lo + 1] = (uint16_t)(nKeep + L.succ[t]); N.ring[lo + 2] = L.newidx[u];
+                }
+            }
+        }
+        nv = nKeep + M;
+        cur ^= 1u;
+        __syncthreads();
+    }
+    *which = cur;
+    if (lane == 0) L.nv[cur] = nv;
+    __syncthreads();
+    return 0;
+}
+
+// Writes the result of small_clip to the arena as one packed solid (the layout park_topo writes).  One wave.
+__device__ inline int sc_park(const ScSolid& S, uint32_t nv, Shared& sh, uint32_t* cursors, float* apos, uint32_t* aloff, uint32_t* allen, int32_t* anbr,
+                              uint32_t capV, uint32_t capH, uint32_t& voff, uint32_t& n, uint32_t& hoff, uint32_t& nh)
+{
+    const uint32_t H = (uint32_t)S.loff[nv - 1u] + S.llen[nv - 1u];
+    __syncthreads();
+    if (threadIdx.x == 0) { sh.misc[0] = atomicAdd(&cursors[0], nv); sh.misc[1] = atomicAdd(&cursors[1], H); }
+    __syncthreads();
+    voff = sh.misc[0]; hoff = sh.misc[1];
+    __syncthreads();
+    if ((uint64_t)voff + nv > capV || (uint64_t)hoff + H > capH) return SURTR_E_CAPACITY;
+    for (uint32_t v = lane_id(); v < nv; v += SURTR_LANES)
+    {
+        const size_t id = (size_t)voff + v;
+        apos[3 * id] = S.pos[3 * v]; apos[3 * id + 1] = S.pos[3 * v + 1]; apos[3 * id + 2] = S.pos[3 * v + 2];
+        const uint32_t lo = hoff + S.loff[v], len = S.llen[v];
+        aloff[id] = lo; allen[id] = len;
+        const uint16_t* r = S.ring + S.loff[v];
+        for (uint32_t q = 0; q < len; ++q) anbr[lo + q] = (int32_t)r[q];
+    }
+    n = nv; nh = H;
+    __syncthreads();
+    return 0;
+}
+
+} // namespace surtr

@@ -24,6 +24,8 @@
 #include <vector>
 
 #include "surtr_ctx.h"
+#include "small_clip.h"
+#include "literal_clip.h"
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
 template <uint32_t LV, uint32_t LH>
@@ -65,6 +67,10 @@ struct LdsWorkT
     int8_t gcomp[N];
 };
 typedef LdsWorkT<LdsTopoSmall::kLV> LdsWorkSmall;
+// LDS of a one-wave kernel: the regular small-solid clipper (small_clip.h) and the general one-wave clipper take turns on the
+// same bytes (a task is tried by the first and, when it is not regular, redone from its input by the second).
+struct OneWaveGeneral { LdsTopoSmall L; LdsWorkSmall W; };
+union alignas(16) OneWaveLds { OneWaveGeneral g; ScLds f; };
 struct NoLdsWork { static constexpr uint32_t kN = 0; };
 
 template <class LT>
@@ -503,6 +509,55 @@ __device__ __attribute__((noinline)) static ParkOut solid_global(SolidIn in, uin
     return o;
 }
 
+// Last resort of the one-wave kernels for a solid whose clip raised SURTR_E_TOPOLOGY in the parallel clipper: the literal,
+// single-lane ClipPolyhedron of literal_clip.h on the workgroup's global scratch, result parked like park_topo's.  Out of line,
+// everything by value (see pair_global).  o.err: 0 (o.n == 0: the reference's answer is "empty") or the error that stands.
+struct LitRun { int err; uint32_t n, nh; LitSolid LS; const uint32_t* off; };
+__device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp)
+{
+    Shared& sh = *shp;
+    Scratch S = carve(pool, wg);
+    const uint32_t capV = S.CV < S.CH / LIT_STRIDE ? S.CV : S.CH / LIT_STRIDE;
+    LitRun r{SURTR_E_TOPOLOGY, 0u, 0u, LitSolid{S.pos, S.g_loff, (int32_t*)S.g_ring, S.g_llen, (int32_t*)S.t_ring, S.g_comp, (int32_t*)S.aux0, capV}, S.aux1};
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t n = 0;
+        int rc = literal_clip(in, F, sh.planes, r.LS, &n);
+        if (rc == SURTR_E_CAPACITY) rc = SURTR_E_TOPOLOGY;          // too large for the literal path: the first error stands
+        uint32_t h = 0;
+        if (rc == 0) for (uint32_t v = 0; v < n; ++v) { S.aux1[v] = h; h += r.LS.len[v]; }
+        sh.misc[2] = (uint32_t)rc; sh.misc[3] = n; sh.misc[4] = h;
+    }
+    __syncthreads();
+    r.err = (int)sh.misc[2]; r.n = sh.misc[3]; r.nh = sh.misc[4];
+    __syncthreads();
+    return r;
+}
+__device__ static void literal_write(const LitRun& r, float* pos, uint32_t* loff, uint32_t* llen, int32_t* nbr, uint32_t voff, uint32_t hoff)
+{
+    for (uint32_t v = threadIdx.x; v < r.n; v += group_size())
+    {
+        const size_t id = (size_t)voff + v;
+        pos[3 * id] = r.LS.pos[3 * v]; pos[3 * id + 1] = r.LS.pos[3 * v + 1]; pos[3 * id + 2] = r.LS.pos[3 * v + 2];
+        const uint32_t lo = hoff + r.off[v], len = r.LS.len[v];
+        loff[id] = lo; llen[id] = len;
+        for (uint32_t q = 0; q < len; ++q) nbr[lo + q] = r.LS.ring[v * LIT_STRIDE + q];
+    }
+    __syncthreads();
+}
+__device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp)
+{
+    const LitRun r = literal_run(in, F, pool, wg, shp);
+    ParkOut o{r.err, 0u, 0u, 0u, 0u};
+    if (r.err != 0 || r.n == 0u) return o;
+    uint32_t ioff;
+    if (!arena_take(A, *shp, r.n, r.nh, 0, o.voff, o.hoff, ioff)) { o.err = SURTR_E_CAPACITY; return o; }
+    literal_write(r, A.pos, A.loff, A.llen, A.nbr, o.voff, o.hoff);
+    o.n = r.n; o.nh = r.nh;
+    return o;
+}
+
 #ifndef SURTR_SMALL_WAVES
 #define SURTR_SMALL_WAVES 2
 #endif
@@ -514,8 +569,8 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                                                     const uint32_t* __restrict__ pair_order)
 {
     __shared__ Shared sh;
-    __shared__ LdsTopoSmall L;
-    __shared__ LdsWorkSmall W;
+    __shared__ OneWaveLds U;
+    LdsTopoSmall& L = U.g.L; LdsWorkSmall& W = U.g.W;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     while (true)
@@ -546,17 +601,45 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             const uint32_t c0 = P.cvo[piece];
             SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
                         P.cperm + c0, P.cposr_s + c0, P.cbsph + P.cbo[piece]};
-            err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
-                if (T.nLive == 0) return 0;
-                return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
-            }, &W);
+            uint32_t which = 0;
+#ifdef SURTR_NO_SMALL_CLIP      // (diagnostic builds: the general clipper alone)
+            err = SC_FALLBACK;
+#else
+            err = small_clip(cin, F, sh, U.f, &which);
+#endif
+            if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 80 : 81], 1u);       // (diagnostic: tasks the regular clipper took / handed on)
+            if (err == 0)
+            {
+                const uint32_t nv = U.f.nv[which];
+                if (nv != 0u) err = sc_park(U.f.buf[which], nv, sh, A.cursors, A.pos, A.loff, A.llen, A.nbr, A.capV, A.capH, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
+            }
             __syncthreads();
+            if (err == SC_FALLBACK)
+            {
+                err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
+                    if (T.nLive == 0) return 0;
+                    return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
+                }, &W);
+                __syncthreads();
+            }
             if (err == SURTR_OVERFLOW)
             {
                 const ParkOut o = solid_global(cin, F, pool, blockIdx.x, A, &sh);
                 err = o.err; rec.cv_off = o.voff; rec.cv_n = o.n; rec.ch_off = o.hoff; rec.ch_n = o.nh;
                 __syncthreads();
             }
+        }
+        if (err == SURTR_E_TOPOLOGY)
+        {
+            // the parallel relink met a walk it cannot follow (a degenerate sliver): the literal single-lane clip has the
+            // reference's answer wherever the reference has one (mostly "empty")
+            const uint32_t c0 = P.cvo[piece];
+            const SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
+                              P.cperm + c0, P.cposr_s + c0, P.cbsph + P.cbo[piece]};
+            const ParkOut o = solid_literal(cin, F, pool, blockIdx.x, A, &sh);
+            if (o.err == 0) { err = 0; rec.cv_off = o.voff; rec.cv_n = o.n; rec.ch_off = o.hoff; rec.ch_n = o.nh; }
+            else if (o.err != SURTR_E_TOPOLOGY) err = o.err;
+            __syncthreads();
         }
         if (err == SURTR_E_TOPOLOGY) { rec.cv_bad = 1; rec.cv_off = 0; rec.cv_n = 1; rec.ch_off = 0; rec.ch_n = 0; err = 0; }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
@@ -1173,6 +1256,8 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
+        // (no small_clip attempt here: the slab planes pass through extreme vertices of the fragment, which are vertices of its
+        // Convex as often as not -- measured on configs[3]: 2 385 of 2 692 refits have a vertex exactly in a plane)
         int err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
             if (T.nLive == 0) return 0;
             return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
@@ -1182,6 +1267,13 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         {
             const ParkOut o = solid_global(cin, 8, pool, blockIdx.x, A, &sh);
             err = o.err; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh;
+            __syncthreads();
+        }
+        if (err == SURTR_E_TOPOLOGY)
+        {
+            const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh);
+            if (o.err == 0) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
+            else if (o.err != SURTR_E_TOPOLOGY) err = o.err;
             __syncthreads();
         }
         if (err == 0 && tid == 0)
@@ -1921,6 +2013,13 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
         return 0;
     });
     __syncthreads();
+    if (err == SURTR_E_TOPOLOGY)
+    {
+        const LitRun r = literal_run(in, F, pool, 0, &sh);
+        if (r.err == 0 && (r.n > cap_v || r.nh > cap_h)) err = SURTR_E_CAPACITY;
+        else if (r.err == 0) { literal_write(r, opos, ooff, ollen, onbr, 0, 0); n = r.n; nh = r.nh; err = 0; }
+        else if (r.err != SURTR_E_TOPOLOGY) err = r.err;
+    }
     if (threadIdx.x == 0) { if (err == 0) ooff[n] = nh; result[0] = n; result[1] = nh; result[2] = (uint32_t)err; }
 }
 

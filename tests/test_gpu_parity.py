@@ -474,6 +474,18 @@ def test_refracture_fuzz_case_264_whole(gpu_engine, oracle):
     assert_event_equal(got, ref)
 
 
+def test_degenerate_walk_bound_pair(gpu_engine, oracle):
+    """Refracture fuzz seed 555, case 110: a sliver piece whose Convex the reference clips to nothing through a relink walk
+    that hits its step bound (tests/test_literal_clip.py) -- single solids, then the whole event (200 first-level cells of a
+    189 x 91 torus, 3 cells per piece)."""
+    import test_literal_clip as _lc
+    from test_refracture import _refracture
+    _lc.check_degenerate_pair(gpu_engine, oracle)
+    c, got, ref, npieces = _refracture(gpu_engine, oracle, 200, 3, 189, 91)
+    assert c.status == 0 and c.n_failed == 0
+    assert_event_equal(got, ref)
+
+
 @pytest.mark.parametrize("name,n", [("urchin64", 64), ("urchin1024", 1024)])
 def test_deep_lobed_mesh_islands(gpu_engine, oracle, name, n):
     """cfg2 / cfg3 cell counts on the deep-lobed mesh (meshgen.urchin): at least a tenth of the non-empty cells hold two or

@@ -1,0 +1,150 @@
+"""literal_clip.h -- the one-lane, statement-by-statement ClipPolyhedron the kernels fall back to when the parallel relink
+meets a face walk it cannot follow (Src/Poly.cpp:389-394 running into its step bound on a degenerate sliver).
+
+CPU tier: the header alone (tests/emul/literal_probe.cpp) against the oracle on ordinary solids, where both clippers must agree
+bit for bit; then the fuzz-found degenerate pair (refracture fuzz seed 555, case 110 -- tests/golden/
+degenerate_walk_bound_convex.npz: a piece whose Mesh is four coincident-vertex slivers and whose Convex lists neighbours
+twice) through the engine entry points on the emulation.  The GPU tier repeats the second half (tests/test_gpu_parity.py).
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from helpers import fragment
+from surtr_amd import scenes
+
+
+def assert_solid_equal(got, ref):
+    """The literal path runs the reference's statements in the reference's order: bit-exact, coordinates included."""
+    assert got["pos"].shape[0] == ref["pos"].shape[0]
+    assert np.array_equal(got["off"], ref["off"]) and np.array_equal(got["nbr"], ref["nbr"])
+    assert np.array_equal(np.asarray(got["pos"], np.float32).reshape(-1, 3), np.asarray(ref["pos"], np.float32).reshape(-1, 3))
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _probe(emul_lib_path):
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(emul_lib_path), "libliteral_probe.so"))
+    lib.literal_probe.restype = ctypes.c_int
+    return lib
+
+
+def _literal(lib, solid, planes, cap_v=512):
+    pos = np.ascontiguousarray(solid["pos"], np.float32); off = np.ascontiguousarray(solid["off"], np.uint32)
+    nbr = np.ascontiguousarray(solid["nbr"], np.int32); pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+    opos = np.zeros((cap_v, 3), np.float32); ooff = np.zeros(cap_v + 1, np.uint32); onbr = np.zeros(cap_v * 32, np.int32)
+    n = ctypes.c_uint32(0)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.literal_probe(ctypes.c_uint32(pos.shape[0]), P(pos), P(off), P(nbr), ctypes.c_uint32(pl.shape[0]), P(pl),
+                           ctypes.c_uint32(cap_v), P(opos), P(ooff), P(onbr), ctypes.byref(n))
+    if rc != 0:
+        return rc, None
+    k = n.value
+    return 0, {"pos": opos[:k].copy(), "off": ooff[:k + 1].copy(), "nbr": onbr[:ooff[k]].copy()}
+
+
+def load_degenerate_pair():
+    d = np.load(os.path.join(HERE, "golden", "degenerate_walk_bound_convex.npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    return mesh, conv, d["planes"]
+
+
+def check_degenerate_pair(E, oracle):
+    """Both solids of the pair through clip_polyhedron: the engine's answer is the oracle's (the Convex comes back empty)."""
+    mesh, conv, planes = load_degenerate_pair()
+    eng = E.Engine(0)
+    try:
+        for s in (mesh, conv):
+            ref = oracle.clip(s, planes)
+            got = eng.clip_polyhedron(s, planes)
+            assert_solid_equal(got, ref)
+        assert oracle.clip(conv, planes)["pos"].shape[0] == 0
+        # plane by plane as well: the clip that empties the Convex is the second
+        cur_e, cur_o = conv, conv
+        for k in range(planes.shape[0]):
+            cur_o = oracle.clip(cur_o, planes[k:k + 1])
+            cur_e = eng.clip_polyhedron(cur_e, planes[k:k + 1])
+            assert_solid_equal(cur_e, cur_o)
+            if cur_o["pos"].shape[0] == 0:
+                break
+    finally:
+        eng.close()
+
+
+def test_literal_equals_oracle_on_regular_solids(emul_lib_path, oracle):
+    """Cells of a 12-cell pattern against the blob's Mesh and Convex, then random plane sets against the resulting fragments."""
+    lib = _probe(emul_lib_path)
+    rng = np.random.default_rng(5)
+    sc = scenes.blob_scene(12)
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    fo = sc["face_off"]
+    n_checked = 0
+    frags = []
+    for c in range(12):
+        pl = planes[fo[c]:fo[c + 1]]
+        for s in (sc["mesh"], sc["convex"]):
+            ref = oracle.clip(s, pl)
+            rc, got = _literal(lib, s, pl, cap_v=4096)
+            assert rc == 0
+            assert_solid_equal(got, ref)
+            n_checked += 1
+            if ref["pos"].shape[0]:
+                frags.append(ref)
+    for s in frags:
+        ctr = s["pos"].mean(0)
+        for _ in range(4):
+            k = int(rng.integers(1, 7))
+            nrm = rng.normal(size=(k, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            d = -(nrm @ ctr) + rng.uniform(-2.0, 8.0, size=k)
+            pl = np.concatenate([nrm, d[:, None]], axis=1).astype(np.float32)
+            ref = oracle.clip(s, pl)
+            rc, got = _literal(lib, s, pl, cap_v=4096)
+            assert rc == 0
+            assert_solid_equal(got, ref)
+            n_checked += 1
+    assert n_checked >= 60
+
+
+def test_literal_in_plane_vertices(emul_lib_path, oracle):
+    """Planes through vertices, edges and faces of a cube (comp == 0 paths, :367-425 and the two-neighbour collapse)."""
+    lib = _probe(emul_lib_path)
+    s = oracle.unit_box()
+    h = 0.5
+    planes = [
+        [1, 0, 0, 0], [1, 0, 0, h], [-1, 0, 0, h], [1, 1, 0, 0], [1, 1, 1, 0], [1, 1, 0, 2 * h], [-1, -1, 0, 2 * h],
+        [1, 1, 1, 3 * h], [-1, -1, -1, 3 * h], [1, 1, 1, h], [-1, -1, -1, h], [0, 1, 0, -h], [0, -1, 0, -h],
+    ]
+    for p in planes:
+        pl = np.asarray([p], np.float32)
+        ref = oracle.clip(s, pl)
+        rc, got = _literal(lib, s, pl)
+        assert rc == 0
+        assert_solid_equal(got, ref)
+    for a in range(len(planes)):
+        for b in range(a + 1, len(planes)):
+            pl = np.asarray([planes[a], planes[b]], np.float32)
+            ref = oracle.clip(s, pl)
+            rc, got = _literal(lib, s, pl)
+            assert rc == 0
+            assert_solid_equal(got, ref)
+
+
+def test_literal_degenerate_pair(emul_lib_path, oracle):
+    lib = _probe(emul_lib_path)
+    mesh, conv, planes = load_degenerate_pair()
+    for s in (mesh, conv):
+        ref = oracle.clip(s, planes)
+        rc, got = _literal(lib, s, planes)
+        assert rc == 0
+        assert_solid_equal(got, ref)
+
+
+def test_engine_degenerate_pair_emulation(emul_engine, oracle):
+    check_degenerate_pair(emul_engine, oracle)
+
+
+def test_engine_degenerate_pair_wide_variant(emul_engine_small, oracle):
+    check_degenerate_pair(emul_engine_small, oracle)
