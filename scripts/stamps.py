@@ -14,6 +14,7 @@ flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 c = eng.fracture_event(0, 4096, flags=flags)
 buf = (ctypes.c_ulonglong * 96)()
 L.surtr_debug_stamps(buf, 1)
+b2z = (ctypes.c_ulonglong * 64)(); L.surtr_debug_stamps2(b2z, 1)
 c = eng.fracture_event(0, 4096, flags=flags)
 L.surtr_debug_stamps(buf, 1)
 names = ["pre: A1 stream", "pre: A2 exact", "pre: emit", "pre: A3 block counts + scan", "plane: classify", "plane: cut links patch", "plane: relink finalize/serial", "plane: tombstones",
@@ -39,7 +40,9 @@ print("one-wave clips: convex kernel: prepass %d, planes %d, park %d over %d tas
 print("refit: hull4 %d, k-DOP %d (lane-0 cycles)" % (buf[94], buf[95]))
 print("select (lane-0 cycles): loop top %d, count+scan %d, write %d" % tuple(buf[76:79]))
 print("prep kernel (lane-0 cycles): planes %d, select %d, image alloc %d, mask copy %d, emit %d, hist+header %d" % tuple(buf[70:76]))
-if flags & 2:
-    print("k_faces: successors %d, pointer jumping %d, owners+loops %d, wave ears %d, lane ears %d, compaction %d; faces > 64 vertices: %d (avg %.1f)" % (buf[60], buf[61], buf[62], buf[63], buf[64], buf[65], buf[66], buf[67] / max(buf[66], 1)))
-    print("k_faces: fragment cost histogram (cycles < 2^15, 2^16, ...):", [buf[70 + i] for i in range(10)], "max", buf[68], "largest slow fragment n", buf[69])
-    print("k_faces: slowest fragment: n %d H %d faces %d | succ %d jump %d own %d wave %d lane %d compact %d" % (buf[69], buf[77], buf[78], buf[32], buf[33], buf[34], buf[35], buf[36], buf[37]))
+b2 = (ctypes.c_ulonglong * 64)()
+L.surtr_debug_stamps2(b2, 0)
+print("k_refit: task cost histogram (cycles < 2^13, 2^14, ...):", [b2[i] for i in range(16)])
+print("k_refit: slowest task %d cycles (mesh n %d, convex n %d); sum %d; WG lifetime avg %.3g max %.3g over %d WGs, most tasks in one WG %d" % (b2[16], b2[17], b2[18], b2[19], b2[20] / max(b2[22], 1), b2[21], b2[22], b2[23]))
+print("k_faces: task cost histogram (cycles < 2^13, 2^14, ...):", [b2[32 + i] for i in range(16)])
+print("k_faces: slowest task %d cycles (n %d H %d faces %d | succ %d jump %d own %d wave %d lane %d compact %d); sum %d; WG lifetime avg %.3g max %.3g over %d WGs" % (b2[48], b2[49], b2[50], b2[55], b2[56], b2[57], b2[58], b2[59], b2[60], b2[61], b2[51], b2[52] / max(b2[54], 1), b2[53], b2[54]))

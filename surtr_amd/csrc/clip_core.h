@@ -45,6 +45,7 @@
 // global table that no product code reads.
 #ifdef SURTR_STAMP
 __device__ unsigned long long g_stamp[96];
+__device__ unsigned long long g_stamp2[64];      // per-task cost of the per-fragment kernels
 #ifdef SURTR_STAMP_SMALL
 #define STAMP_WHO (blockDim.x == 64 && gridDim.x > 1900)
 #else

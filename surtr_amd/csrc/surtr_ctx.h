@@ -193,6 +193,7 @@ static inline bool surtr_fits_half(uint32_t n, uint32_t h) { return fits_half(n,
 struct surtr_ctx
 {
     int device = 0;
+    uint32_t n_wg_faces_alloc = 0;
     uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;
     ScratchPool pool_half{}; uint32_t n_wg_half = 0;       // k_clip_pairs_half: scratch for the half-size LDS topology only
     // Light pairs go to k_clip_pairs_half only when they are most of the event (small pieces: refracture).  Beside a

@@ -1150,6 +1150,10 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
+#ifdef SURTR_STAMP
+    const unsigned long long wg_t0 = __builtin_readcyclecounter();
+    unsigned long long wg_tasks = 0;
+#endif
     while (true)
     {
         __syncthreads();
@@ -1282,7 +1286,20 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             frags[f].cv_off = nvoff; frags[f].cv_n = ncn; frags[f].ch_off = nhoff; frags[f].ch_n = nchn;
         }
         if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
+#ifdef SURTR_STAMP
+        if (tid == 0)
+        {
+            const unsigned long long d = __builtin_readcyclecounter() - r0; ++wg_tasks;
+            int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 12 ? 0 : bkt - 12; if (bkt > 15) bkt = 15;
+            atomicAdd(&g_stamp2[bkt], 1ull); atomicAdd(&g_stamp2[19], d);
+            const unsigned long long old = atomicMax(&g_stamp2[16], d);
+            if (d > old) { g_stamp2[17] = n; g_stamp2[18] = fr.cv_n; }
+        }
+#endif
     }
+#ifdef SURTR_STAMP
+    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp2[20], d); atomicMax(&g_stamp2[21], d); atomicAdd(&g_stamp2[22], 1ull); atomicMax(&g_stamp2[23], wg_tasks); }
+#endif
 }
 
 // ------------------------------------------------------------------ k_faces
@@ -1475,9 +1492,18 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
 {
     __shared__ Shared sh;
     // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
-    constexpr uint32_t FL_V = 1024, FL_H = 4096;
-    __shared__ uint16_t f_loff[FL_V]; __shared__ uint16_t f_llen[FL_V]; __shared__ uint16_t f_nbr[FL_H]; __shared__ uint8_t f_vis[FL_H];
-    __shared__ uint32_t f_cov[FL_H];
+#ifndef SURTR_FL_V
+#define SURTR_FL_V 1024
+#define SURTR_FL_H 4096
+#endif
+    constexpr uint32_t FL_V = SURTR_FL_V, FL_H = SURTR_FL_H, FL_J = SURTR_FL_H / 2u;
+    __shared__ uint16_t f_loff[FL_V]; __shared__ uint16_t f_llen[FL_V]; __shared__ uint16_t f_nbr[FL_H];
+    // the sliver path's visit marks, or (regular fragments of at most FL_J half-edges) the pointer-jumping arrays
+    struct IrrLds { uint8_t vis[FL_H]; uint32_t cov[FL_H]; };
+    struct JumpLds { uint16_t k0[FL_J], k1[FL_J], x0[FL_J], x1[FL_J]; };
+    union FacesLds { IrrLds irr; JumpLds jmp; };
+    __shared__ FacesLds FU;
+    uint8_t* const f_vis = FU.irr.vis; uint32_t* const f_cov = FU.irr.cov;
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
     int32_t* base = FS.base + (size_t)blockIdx.x * FS.per_wg;
@@ -1487,6 +1513,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
     uint32_t* tri = (uint32_t*)(base + 8 * (size_t)HF);                                   // 3*HF
     uint32_t* fcnt = (uint32_t*)(base + 11 * (size_t)HF);                                 // HF (per owner edge)
     uint2* blk = blkpool + (size_t)blockIdx.x * blk_per_wg;
+#ifdef SURTR_STAMP
+    const unsigned long long wg_t0f = __builtin_readcyclecounter();
+#endif
     while (true)
     {
         __syncthreads();
@@ -1508,27 +1537,43 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         // 1. successor half-edge in the face loop; half-edge id = position in the packed ring array.
         //    A ring that lists a neighbour twice (sliver fragments) breaks the one-loop-per-half-edge
         //    property: such fragments take the literal, serial ExtractFaces below.
+        // Fragments are small: the topology is staged in LDS (16-bit) whenever it fits, and the passes below read that copy.
+        const bool topo_lds = n <= FL_V && H <= FL_H && n < 0xFFFFu;
+        const bool jump_lds = topo_lds && H <= FL_J;
         if (tid == 0) sh.flagBad = 0;
-        __syncthreads();
+        if (topo_lds)
         {
+            for (uint32_t v = tid; v < n; v += group_size()) { f_loff[v] = (uint16_t)(loff[v] - fr.mh_off); f_llen[v] = (uint16_t)llen[v]; }
+            for (uint32_t e = tid; e < H; e += group_size()) f_nbr[e] = (uint16_t)nbr[e];
+        }
+        __syncthreads();
+        auto gLO = [&](uint32_t v) -> uint32_t { return loff[v] - fr.mh_off; };
+        auto gLN = [&](uint32_t v) -> uint32_t { return llen[v]; };
+        auto lLO = [&](uint32_t v) -> uint32_t { return f_loff[v]; };
+        auto lLN = [&](uint32_t v) -> uint32_t { return f_llen[v]; };
+        auto successors = [&](auto LO, auto LN, const auto* NB, auto* NX, auto* KEY) {
+            typedef typename std::remove_reference<decltype(NX[0])>::type XT;
             bool dup = false;
             for (uint32_t v = tid; v < n; v += group_size())
             {
-                const uint32_t lo = loff[v] - fr.mh_off, len = llen[v];
+                const uint32_t lo = LO(v), len = LN(v);
                 for (uint32_t s = 0; s < len; ++s)
                 {
-                    const int32_t b = nbr[lo + s];
-                    for (uint32_t s2 = 0; s2 < s; ++s2) if (nbr[lo + s2] == b) dup = true;
-                    const uint32_t lb = loff[b] - fr.mh_off, nbq = llen[b];
+                    const uint32_t b = (uint32_t)NB[lo + s];
+                    for (uint32_t s2 = 0; s2 < s; ++s2) if ((uint32_t)NB[lo + s2] == b) dup = true;
+                    const uint32_t lb = LO(b), nbq = LN(b);
                     uint32_t q = 0;
-                    while (q < nbq && nbr[lb + q] != (int32_t)v) ++q;
+                    while (q < nbq && (uint32_t)NB[lb + q] != v) ++q;
                     const uint32_t sq = (q == 0) ? nbq - 1 : q - 1;   // FaceLoop
-                    nxA[lo + s] = (int32_t)(lb + sq);
-                    keyA[lo + s] = (int32_t)(lo + s);
+                    NX[lo + s] = (XT)(lb + sq);
+                    KEY[lo + s] = (XT)(lo + s);
                 }
             }
             if (dup) sh.flagBad = 1;
-        }
+        };
+        if (jump_lds) successors(lLO, lLN, f_nbr, FU.jmp.x0, FU.jmp.k0);
+        else if (topo_lds) successors(lLO, lLN, f_nbr, nxA, keyA);
+        else successors(gLO, gLN, nbr, nxA, keyA);
         __syncthreads();
         STAMP(60);
         bool irregular = sh.flagBad != 0;
@@ -1544,6 +1589,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         for (int attempt = 0; attempt < 2; ++attempt)
         {
         nfaces = 0; lensum = 0; faceLo = nxB; faceLen = keyB; serial_extract = false; kc = keyA;
+        const uint16_t* own16 = nullptr;      // LDS pointer jumping: per half-edge the smallest half-edge of its loop
         staged = irregular && n <= FL_V && H <= FL_H;
         bool pinched = false;
         if (irregular)
@@ -1621,6 +1667,25 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 faceLo = nxB; faceLen = keyB;
             }
         }
+        else if (jump_lds)
+        {
+            // 2. minimum half-edge id of every loop by pointer jumping, on the LDS arrays
+            uint16_t* k16 = FU.jmp.k0; uint16_t* kn = FU.jmp.k1; uint16_t* xc = FU.jmp.x0; uint16_t* xn = FU.jmp.x1;
+            for (uint32_t span = 1; span < H; span <<= 1)
+            {
+                for (uint32_t e = tid; e < H; e += group_size())
+                {
+                    const uint32_t t = xc[e];
+                    const uint16_t a = k16[e], b = k16[t];
+                    kn[e] = a < b ? a : b;
+                    xn[e] = xc[t];
+                }
+                __syncthreads();
+                uint16_t* t1 = k16; k16 = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
+            }
+            own16 = k16;
+            STAMP(61);
+        }
         else
         {
             // 2. minimum half-edge id of every loop by pointer jumping
@@ -1643,51 +1708,57 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         if (!serial_extract)
         {
             // 3. faces = owner half-edges in ascending order (ExtractFaces visiting order, Src/Poly.cpp:94-122)
-            auto vertex_of = [&](uint32_t e) -> uint32_t {
-                uint32_t lo_v = 0, hi_v = n;
-                while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (loff[mid] - fr.mh_off <= e) lo_v = mid; else hi_v = mid; }
-                return lo_v;
-            };
-            auto ownfn = [&](uint32_t e) -> uint2 {
-                if (kc[e] != (int32_t)e) return make_uint2(0u, 0u);
-                const int32_t start = (int32_t)vertex_of(e);
-                int32_t prev = start, curv = nbr[e];
-                uint32_t len = 1;
-                while (curv != start && len <= H)
-                {
-                    const uint32_t lc = loff[curv] - fr.mh_off;
-                    const int32_t nx = face_next(nbr + lc, llen[curv], prev);
-                    prev = curv; curv = nx; ++len;
-                }
-                return make_uint2(1u, len);
-            };
-            scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
-            if (lensum > HF) { failed = true; break; }
-            if (!irregular && lensum != H) pinched = true;
-            const uint32_t nb = pinched ? 0u : (H + SURTR_LANES - 1u) >> SURTR_LSH;
-            for (uint32_t b = wave_id(); b < nb; b += group_waves())
-            {
-                const uint32_t e = (b << SURTR_LSH) + lane_id();
-                uint2 c = make_uint2(0u, 0u);
-                if (e < H) c = ownfn(e);
-                const uint2 ex = wave_excl2(c);
-                if (e < H && c.x)
-                {
-                    const uint32_t fi = blk[b].x + ex.x, lo = blk[b].y + ex.y;
-                    int32_t* loop = loopbuf + lo;
-                    const int32_t start = (int32_t)vertex_of(e);
-                    int32_t prev = start, curv = nbr[e];
-                    uint32_t len = 1; loop[0] = start;
-                    while (curv != start && len < c.y)
+            auto owners = [&](auto LO, auto LN, const auto* NB, auto OWN) {
+                auto vertex_of = [&](uint32_t e) -> uint32_t {
+                    uint32_t lo_v = 0, hi_v = n;
+                    while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (LO(mid) <= e) lo_v = mid; else hi_v = mid; }
+                    return lo_v;
+                };
+                auto ownfn = [&](uint32_t e) -> uint2 {
+                    if (!OWN(e)) return make_uint2(0u, 0u);
+                    const uint32_t start = vertex_of(e);
+                    uint32_t prev = start, curv = (uint32_t)NB[e];
+                    uint32_t len = 1;
+                    while (curv != start && len <= H)
                     {
-                        loop[len++] = curv;
-                        const uint32_t lc = loff[curv] - fr.mh_off;
-                        const int32_t nx = face_next(nbr + lc, llen[curv], prev);
-                        prev = curv; curv = nx;
+                        const uint32_t nx = (uint32_t)face_next(NB + LO(curv), LN(curv), prev);
+                        prev = curv; curv = nx; ++len;
                     }
-                    faceLo[fi] = (int32_t)lo; faceLen[fi] = (int32_t)len;
+                    return make_uint2(1u, len);
+                };
+                scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
+                if (lensum > HF) return false;
+                if (!irregular && lensum != H) pinched = true;
+                const uint32_t nb = pinched ? 0u : (H + SURTR_LANES - 1u) >> SURTR_LSH;
+                for (uint32_t b = wave_id(); b < nb; b += group_waves())
+                {
+                    const uint32_t e = (b << SURTR_LSH) + lane_id();
+                    uint2 c = make_uint2(0u, 0u);
+                    if (e < H) c = ownfn(e);
+                    const uint2 ex = wave_excl2(c);
+                    if (e < H && c.x)
+                    {
+                        const uint32_t fi = blk[b].x + ex.x, lo = blk[b].y + ex.y;
+                        int32_t* loop = loopbuf + lo;
+                        const uint32_t start = vertex_of(e);
+                        uint32_t prev = start, curv = (uint32_t)NB[e];
+                        uint32_t len = 1; loop[0] = (int32_t)start;
+                        while (curv != start && len < c.y)
+                        {
+                            loop[len++] = (int32_t)curv;
+                            const uint32_t nx = (uint32_t)face_next(NB + LO(curv), LN(curv), prev);
+                            prev = curv; curv = nx;
+                        }
+                        faceLo[fi] = (int32_t)lo; faceLen[fi] = (int32_t)len;
+                    }
                 }
-            }
+                return true;
+            };
+            bool ok;
+            if (own16 != nullptr) ok = owners(lLO, lLN, f_nbr, [&](uint32_t e) { return (uint32_t)own16[e] == e; });
+            else if (topo_lds) ok = owners(lLO, lLN, f_nbr, [&](uint32_t e) { return kc[e] == (int32_t)e; });
+            else ok = owners(gLO, gLN, nbr, [&](uint32_t e) { return kc[e] == (int32_t)e; });
+            if (!ok) { failed = true; break; }
         }
         else
         {
@@ -1832,9 +1903,19 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         if (tid == 0) { frags[f].idx_off = ioff; frags[f].idx_n = nidx; }     // field-wise: k_refit runs beside this kernel
         STAMP(65);
 #ifdef SURTR_STAMP
-        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - frag_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 14 ? 0 : bkt - 14; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[70 + bkt], 1ull); const unsigned long long old = atomicMax(&g_stamp[68], d); if (d > old) { g_stamp[69] = n; g_stamp[61 + 16] = H; g_stamp[62 + 16] = nfaces; for (int q = 0; q < 6; ++q) g_stamp[32 + q] = sh.ph[(60 + q) & 15]; } }
+        if (tid == 0)
+        {
+            const unsigned long long d = __builtin_readcyclecounter() - frag_t0;
+            int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 12 ? 0 : bkt - 12; if (bkt > 15) bkt = 15;
+            atomicAdd(&g_stamp2[32 + bkt], 1ull); atomicAdd(&g_stamp2[51], d);
+            const unsigned long long old = atomicMax(&g_stamp2[48], d);
+            if (d > old) { g_stamp2[49] = n; g_stamp2[50] = H; g_stamp2[55] = nfaces; for (int q = 0; q < 6; ++q) g_stamp2[56 + q] = sh.ph[(60 + q) & 15]; }
+        }
 #endif
     }
+#ifdef SURTR_STAMP
+    if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0f; atomicAdd(&g_stamp2[52], d); atomicMax(&g_stamp2[53], d); atomicAdd(&g_stamp2[54], 1ull); }
+#endif
 }
 
 // --------------------------------------------------------------- k_out_scan
@@ -2205,7 +2286,9 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
 
 static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint32_t n_wg)
 {
-    const uint32_t n_wg_faces = std::max(n_wg, ctx->max_wg_faces);
+    uint32_t n_wg_faces = std::max(n_wg, ctx->max_wg_faces);
+    if (const char* e = getenv("SURTR_FACES_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > n_wg_faces && v <= 8192u) n_wg_faces = v; }
+    ctx->n_wg_faces_alloc = n_wg_faces;
     // Tombstones keep every vertex ever created in its slot, so the wide (global) variant is sized for
     // the band plus all cuts; the LDS variant has fixed capacities (SURTR_LV / SURTR_LH).
     uint32_t CV = ctx->user_cv ? ctx->user_cv : 2 * need_v + 4096;
@@ -2472,13 +2555,19 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (flags & SURTR_EVT_REFIT)
     {
         PROF_BEGIN_ON(2, st_refit);
-        hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
+        uint32_t g_refit = ctx->n_wg_small;
+        if (both) if (const char* e = getenv("SURTR_REFIT_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v < g_refit) g_refit = v; }
+        hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
         PROF_END_ON(2, st_refit);
     }
     if (flags & SURTR_EVT_RENDER)
     {
         PROF_BEGIN(3);
-        hipLaunchKernelGGL(k_faces, dim3(std::max(n_wg, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
+        uint32_t g_faces = std::max(n_wg, ctx->max_wg_faces), t_faces = SURTR_WG;
+        if (both) if (const char* e = getenv("SURTR_FACES_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v < g_faces) g_faces = v; }
+        if (const char* e = getenv("SURTR_FACES_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_faces_alloc) g_faces = v; }
+        if (const char* e = getenv("SURTR_FACES_THREADS")) { const uint32_t v = (uint32_t)atoi(e); if (v == 64 || v == 128 || v == 256) t_faces = v; }
+        hipLaunchKernelGGL(k_faces, dim3(g_faces), dim3(t_faces), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
                            ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
                            ctx->d_frag_status);
         PROF_END(3);
@@ -2826,6 +2915,12 @@ int surtr_event_pack_dev(surtr_ctx* ctx, void* dev_blob, size_t capacity)
 }
 
 #ifdef SURTR_STAMP
+int surtr_debug_stamps2(unsigned long long out[64], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp2), sizeof(unsigned long long) * 64) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(z)); }
+    return SURTR_OK;
+}
 int surtr_debug_stamps(unsigned long long out[96], int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 96) != hipSuccess) return SURTR_E_HIP;
