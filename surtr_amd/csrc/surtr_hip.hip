@@ -1162,11 +1162,19 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         const uint32_t f = sh.misc[7];
         if (f >= nf) break;
         FragRec fr = frags[f];
-        const float* mp = A.pos + 3 * (size_t)fr.mv_off;
+        const float* mpg = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t n = fr.mv_n;
 #ifdef SURTR_STAMP
         const unsigned long long r0 = __builtin_readcyclecounter();
 #endif
+        // The fragment's vertices are read a dozen times (four hull passes, eight slab extremes): a fragment of up to
+        // 2 * LdsWorkSmall::kN vertices is staged once in the LDS work arrays, which nothing uses before the clip below.
+#ifdef SURTR_STAMP
+        unsigned long long r1 = 0;
+#endif
+        static_assert(offsetof(LdsWorkSmall, aux0) == sizeof(float) * 3 * LdsWorkSmall::kN && offsetof(LdsWorkSmall, aux1) == sizeof(float) * 4 * LdsWorkSmall::kN &&
+                      offsetof(LdsWorkSmall, aux2) == sizeof(float) * 5 * LdsWorkSmall::kN, "pos, aux0, aux1, aux2 are contiguous");
+        auto slabs = [&](const auto* mp) {
         // ---- BuildFirstHull (Src/VMACH.cpp:1036-1085) with limit min(n,4) = 4 ----
         ArgF a; a.i = 0xFFFFFFFFu; a.v = 0.f;
         for (uint32_t v = tid; v < n; v += group_size())
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         }
         __syncthreads();
 #ifdef SURTR_STAMP
-        const unsigned long long r1 = __builtin_readcyclecounter();
+        r1 = __builtin_readcyclecounter();
 #endif
         // ---- Kdop::Calc(Polyhedron) (Src/Kdop.cpp:92-115): first minimum / first maximum of n.v ----
         for (int k = 0; k < 4; ++k)
@@ -1254,8 +1262,20 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
         }
         __syncthreads();
+        };
+        if (n <= 2u * LdsWorkSmall::kN)
+        {
+            float* lp = W.pos;
+            for (uint32_t i = tid; i < 3u * n; i += group_size()) lp[i] = mpg[i];
+            __syncthreads();
+            slabs((const float*)lp);
+            __syncthreads();
+        }
+        else slabs(mpg);
 #ifdef SURTR_STAMP
-        if (tid == 0) { const unsigned long long r2 = __builtin_readcyclecounter(); atomicAdd(&g_stamp[94], r1 - r0); atomicAdd(&g_stamp[95], r2 - r1); }
+        const unsigned long long r2 = __builtin_readcyclecounter();
+        if (tid == 0) { atomicAdd(&g_stamp[94], r1 - r0); atomicAdd(&g_stamp[95], r2 - r1); }
+        int dbg_path = 0;
 #endif
         SolidIn cin{A.pos + 3 * (size_t)fr.cv_off, A.loff + fr.cv_off, A.llen + fr.cv_off, A.nbr, fr.cv_n, nullptr, nullptr, nullptr, nullptr, nullptr};
         // arena rings are absolute offsets into A.nbr, which is what SolidIn expects
@@ -1267,12 +1287,19 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
         }, &W);
         __syncthreads();
+#ifdef SURTR_STAMP
+        if (err == SURTR_OVERFLOW) dbg_path |= 1;
+        if (err == SURTR_E_TOPOLOGY) dbg_path |= 2;
+#endif
         if (err == SURTR_OVERFLOW)
         {
             const ParkOut o = solid_global(cin, 8, pool, blockIdx.x, A, &sh);
             err = o.err; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh;
             __syncthreads();
         }
+#ifdef SURTR_STAMP
+        if (err == SURTR_E_TOPOLOGY) dbg_path |= 4;
+#endif
         if (err == SURTR_E_TOPOLOGY)
         {
             const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh);
@@ -1293,7 +1320,9 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 12 ? 0 : bkt - 12; if (bkt > 15) bkt = 15;
             atomicAdd(&g_stamp2[bkt], 1ull); atomicAdd(&g_stamp2[19], d);
             const unsigned long long old = atomicMax(&g_stamp2[16], d);
-            if (d > old) { g_stamp2[17] = n; g_stamp2[18] = fr.cv_n; }
+            if (d > old) { g_stamp2[17] = n; g_stamp2[18] = fr.cv_n; g_stamp2[60] = r1 - r0; g_stamp2[61] = r2 - r1; g_stamp2[62] = (unsigned long long)dbg_path; g_stamp2[63] = ncn; }
+            if (dbg_path & 1) atomicAdd(&g_stamp2[30], 1ull);
+            if (dbg_path & 6) atomicAdd(&g_stamp2[31], 1ull);
         }
 #endif
     }
@@ -1852,12 +1881,22 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             }
         }
 #if SURTR_LANES == 64
-        for (uint32_t fi = wave_id(); fi < (fan ? 0u : nfaces); fi += group_waves())
+        // every wave reads the lengths of 64 faces at a time (one round trip) and takes every group_waves()-th face of 5..64
+        // vertices among them: most faces are triangles, and a wave that looked at them one by one spent its time waiting
+        for (uint32_t f0 = 0; f0 < (fan ? 0u : nfaces); f0 += SURTR_LANES)
         {
-            const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
-            if (len < 5u || len > 64u) continue;
-            const uint32_t cnt = ear_clip_face_wave(pos, loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
-            if (lane_id() == 0) fcnt[fi] = cnt;
+            const uint32_t fl = f0 + lane_id();
+            uint32_t mylo = 0, mylen = 0;
+            if (fl < nfaces) { mylo = (uint32_t)faceLo[fl]; mylen = (uint32_t)faceLen[fl]; }
+            unsigned long long todo = __ballot(mylen >= 5u && mylen <= 64u);
+            for (uint32_t ord = 0; todo != 0ull; todo &= todo - 1ull, ++ord)
+            {
+                if (ord % group_waves() != wave_id()) continue;
+                const uint32_t src = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t lo = lane_bcast(mylo, src), len = lane_bcast(mylen, src);
+                const uint32_t cnt = ear_clip_face_wave(pos, loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
+                if (lane_id() == 0) fcnt[f0 + src] = cnt;
+            }
         }
         __syncthreads();
         STAMP(63);
@@ -1908,6 +1947,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             const unsigned long long d = __builtin_readcyclecounter() - frag_t0;
             int bkt = 0; while ((d >> bkt) > 1 && bkt < 40) ++bkt; bkt = bkt < 12 ? 0 : bkt - 12; if (bkt > 15) bkt = 15;
             atomicAdd(&g_stamp2[32 + bkt], 1ull); atomicAdd(&g_stamp2[51], d);
+            for (int q = 0; q < 6; ++q) atomicAdd(&g_stamp2[24 + q], sh.ph[(60 + q) & 15]);
             const unsigned long long old = atomicMax(&g_stamp2[48], d);
             if (d > old) { g_stamp2[49] = n; g_stamp2[50] = H; g_stamp2[55] = nfaces; for (int q = 0; q < 6; ++q) g_stamp2[56 + q] = sh.ph[(60 + q) & 15]; }
         }
