@@ -2595,8 +2595,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (flags & SURTR_EVT_REFIT)
     {
         PROF_BEGIN_ON(2, st_refit);
+        // side by side the two kernels share the CUs' registers and LDS: k_faces at two workgroups per CU leaves room for five
+        // of k_refit's (measured on configs[3]: 3.72 -> 3.65 ms per event against both at their stand-alone sizes)
         uint32_t g_refit = ctx->n_wg_small;
-        if (both) if (const char* e = getenv("SURTR_REFIT_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v < g_refit) g_refit = v; }
+        if (both) g_refit = std::min(g_refit, ctx->max_wg_faces / 4u * 5u);
+        if (both) if (const char* e = getenv("SURTR_REFIT_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_small) g_refit = v; }
         hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
         PROF_END_ON(2, st_refit);
     }
@@ -2604,7 +2607,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     {
         PROF_BEGIN(3);
         uint32_t g_faces = std::max(n_wg, ctx->max_wg_faces), t_faces = SURTR_WG;
-        if (both) if (const char* e = getenv("SURTR_FACES_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v < g_faces) g_faces = v; }
+        if (both) g_faces = std::max(1u, ctx->max_wg_faces / 2u);
+        if (both) if (const char* e = getenv("SURTR_FACES_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_faces_alloc) g_faces = v; }
         if (const char* e = getenv("SURTR_FACES_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_faces_alloc) g_faces = v; }
         if (const char* e = getenv("SURTR_FACES_THREADS")) { const uint32_t v = (uint32_t)atoi(e); if (v == 64 || v == 128 || v == 256) t_faces = v; }
         hipLaunchKernelGGL(k_faces, dim3(g_faces), dim3(t_faces), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
