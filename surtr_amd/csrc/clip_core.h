@@ -36,6 +36,8 @@
 #ifndef SURTR_WG
 #define SURTR_WG 256
 #endif
+#define SURTR_WG_WIDE (4u * SURTR_WG)        // k_prep_pairs_wide: events of so few pairs that every pair gets a quarter of a CU
+#define SURTR_NWAVE_WIDE (SURTR_WG_WIDE / SURTR_LANES)
 #define SURTR_NWAVE (SURTR_WG / SURTR_LANES)   // the LARGEST group a kernel is launched with; smaller launches use fewer
 #ifndef SURTR_DBG
 #define SURTR_DBG(...)
@@ -175,7 +177,7 @@ struct Shared
     uint32_t hist[SURTR_MAXF + 1];    // after the pre-pass: dropped vertices still alive after plane k
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t nzero[SURTR_MAXF + 1];   // vertices of the reduced solid that lie in plane k before any plane clips them (>0: general path)
-    uint32_t wsum[2 * SURTR_NWAVE];
+    uint32_t wsum[2 * SURTR_NWAVE_WIDE];
     uint32_t flagBad, flagErr;
     uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;

@@ -705,9 +705,10 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifndef SURTR_PREP_WAVES
 #define SURTR_PREP_WAVES 7       // workgroups per CU = waves per SIMD: the register budget is set for that (<= 72 VGPRs)
 #endif
-__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs(Pieces P, const float4* __restrict__ planes,
+__device__ __attribute__((always_inline)) static inline void prep_pairs_body(Shared& sh, unsigned long long* lmask, uint2* lblk,
+                                                         const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
-                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
+                                                         uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
                                                          uint32_t* __restrict__ horder, uint32_t half_on)
@@ -716,9 +717,6 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
     auto enqueue = [&](uint32_t p, uint32_t cls) { order[(size_t)cls * n_pairs + atomicAdd(&A.cursors[16u + cls], 1u)] = p; };
     auto enqueue_half = [&](uint32_t p, uint32_t cls) { horder[(size_t)cls * n_pairs + atomicAdd(&A.cursors[64u + cls], 1u)] = p; };
-    __shared__ Shared sh;
-    __shared__ unsigned long long lmask[SURTR_PREP_NB];
-    __shared__ uint2 lblk[SURTR_PREP_NB];
     const uint32_t tid = threadIdx.x;
     char* sp = pool.base + (size_t)blockIdx.x * pool.per_wg;
     auto take = [&](size_t bytes) { char* r = sp; sp += (bytes + 255) & ~(size_t)255; return r; };
@@ -841,6 +839,35 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
 #ifdef SURTR_STAMP
     if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - wg_t0; atomicAdd(&g_stamp[56], d); atomicMax(&g_stamp[57], d); atomicAdd(&g_stamp[58], 1ull); atomicAdd(&g_stamp[59], wg_work); atomicMax(&g_stamp[60], wg_work); }
 #endif
+}
+
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
+                                                         PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
+                                                         uint32_t* __restrict__ horder, uint32_t half_on)
+{
+    __shared__ Shared sh;
+    __shared__ unsigned long long lmask[SURTR_PREP_NB];
+    __shared__ uint2 lblk[SURTR_PREP_NB];
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on);
+}
+
+// The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
+// regular launch leaves most of the chip idle while every pair waits for its own 50 000 vertices: the passes over the
+// vertices are data parallel, so a pair is done in about a third of the time.
+__global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
+                                                         PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
+                                                         uint32_t* __restrict__ horder, uint32_t half_on)
+{
+    __shared__ Shared sh;
+    __shared__ unsigned long long lmask[SURTR_PREP_NB];
+    __shared__ uint2 lblk[SURTR_PREP_NB];
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -2542,7 +2569,15 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order);
     PROF_END(6);
     PROF_BEGIN(7);
-    if (n_pairs)
+    // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
+    uint32_t wide_max = 4u * ctx->max_wg;
+    if (const char* e = getenv("SURTR_PREP_WIDE_MAX")) wide_max = (uint32_t)atoi(e);
+    const bool prep_wide = n_pairs != 0 && n_pairs <= wide_max && ctx->vmax >= 8192u;      // few pairs, large meshes
+    if (n_pairs && prep_wide)
+        hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u);
+    else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
                            ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u);
