@@ -36,7 +36,11 @@
 #ifndef SURTR_WG
 #define SURTR_WG 256
 #endif
+#if SURTR_LANES == 64
 #define SURTR_WG_WIDE (4u * SURTR_WG)        // k_prep_pairs_wide: events of so few pairs that every pair gets a quarter of a CU
+#else
+#define SURTR_WG_WIDE SURTR_WG               // (the single-lane CPU build runs one thread per workgroup)
+#endif
 #define SURTR_NWAVE_WIDE (SURTR_WG_WIDE / SURTR_LANES)
 #define SURTR_NWAVE (SURTR_WG / SURTR_LANES)   // the LARGEST group a kernel is launched with; smaller launches use fewer
 #ifndef SURTR_DBG
