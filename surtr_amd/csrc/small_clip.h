@@ -69,7 +69,15 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         if (deg > 15u || deg < 3u) odd = true;
         S.loff[v] = (uint16_t)lo; S.llen[v] = (uint8_t)(deg > 15u ? 15u : deg);
         const int32_t* r = in.nbr + in.loff[v];
-        for (uint32_t j = 0; j < deg && lo + j < SC_H; ++j) S.ring[lo + j] = (uint16_t)r[j];
+        for (uint32_t j = 0; j < deg && lo + j < SC_H; ++j)
+        {
+            S.ring[lo + j] = (uint16_t)r[j];
+            // A ring that lists a vertex twice (slivers) makes the reference's first-occurrence patches and walks order
+            // dependent: the general clipper reproduces that, this one does not try.  Checked once, here: a regular plane
+            // cannot create such a ring in a kept vertex (its clipped neighbours become the distinct new vertices of distinct
+            // edges), and a new vertex [pred, succ, kept] has one only when pred == succ, which the plane loop checks.
+            for (uint32_t jj = 0; jj < j; ++jj) if (r[jj] == r[j]) odd = true;
+        }
     }
     if (__ballot(odd) != 0ull) return SC_FALLBACK;
     __syncthreads();
@@ -92,7 +100,6 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         __syncthreads();
         // ---- new vertices in (clipped vertex, slot) order; kept vertices' new indices and ring offsets ----
         uint32_t carryM = 0, carryK = 0, carryH = 0;
-        bool dup = false;
         for (uint32_t v0 = 0; v0 < nv; v0 += SURTR_LANES)
         {
             const uint32_t v = v0 + lane;
@@ -101,9 +108,6 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             {
                 deg = S.llen[v];
                 const uint16_t* r = S.ring + S.loff[v];
-                // a ring that lists a vertex twice (slivers; a cap of two vertices) makes the reference's first-occurrence
-                // patches and walks order dependent: the general clipper reproduces that, this one does not try
-                for (uint32_t j = 1; j < deg; ++j) for (uint32_t jj = 0; jj < j; ++jj) if (r[jj] == r[j]) dup = true;
                 if (L.c[v] > 0) isKept = 1u;
                 else
                     for (uint32_t j = 0; j < deg; ++j) if (L.c[r[j]] > 0) mask |= 1u << j;
@@ -121,7 +125,6 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             const uint32_t tx = lane_bcast(inc.x, SURTR_LANES - 1u), ty = lane_bcast(inc.y, SURTR_LANES - 1u);
             carryM += tx & 0xFFFFu; carryK += tx >> 16; carryH += ty;
         }
-        if (__ballot(dup) != 0ull) return SC_FALLBACK;
         const uint32_t M = carryM, nKeep = carryK, HK = carryH;
         if (nKeep + M > SC_V || HK + 3u * M > SC_H) return SC_FALLBACK;
         if (nKeep + M < 4u) { nv = 0; break; }                        // (:497-499)
@@ -154,7 +157,8 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         }
         if (__ballot(bad) != 0ull) return SC_FALLBACK;
         __syncthreads();
-        for (uint32_t t = lane; t < M; t += SURTR_LANES) if (L.pred[t] == 0xFFFFu || L.pred[L.succ[t]] != t) bad = true;
+        // (pred == succ: a cap of two vertices, i.e. a new ring that lists a vertex twice)
+        for (uint32_t t = lane; t < M; t += SURTR_LANES) if (L.pred[t] == 0xFFFFu || L.pred[L.succ[t]] != t || L.pred[t] == L.succ[t]) bad = true;
         if (__ballot(bad) != 0ull) return SC_FALLBACK;
         // ---- the solid after this plane, compacted (:464-495): kept vertices in order, then the new ones ----
         for (uint32_t v = lane; v < nv; v += SURTR_LANES)
