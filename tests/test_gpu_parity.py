@@ -594,3 +594,29 @@ def test_graft_entry_smoke():
     """__graft_entry__.smoke(): the one small event the driver runs before the bench."""
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [8, 4, 2])
+def test_sharded_torus_event_equals_the_whole(gpu_engine, oracle, torus_run, world):
+    """The configs[3] event cut into `world` contiguous cell blocks, as the ranks of a strong-sharded run take them (one
+    after the other on this GPU): blocks of at most 2 048 pairs go through k_prep_pairs_wide.  Merged in rank order they
+    are the whole event, bit for bit."""
+    sc, c_all, got_all, ref = torus_run
+    eng = gpu_engine.Engine(0)
+    try:
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        eng.upload_pattern(sc["face_off"], sc["v012"])
+        eng.place_cells(sc["scale"], sc["translate"])
+        parts = []
+        for r in range(world):
+            b, e = gpu_engine.cell_block(r, world, sc["n_cells"])
+            c = eng.fracture_event(b, e, flags=3)
+            assert c.status == 0
+            parts.append(eng.download())
+        merged = gpu_engine.merge_fragments(parts)
+    finally:
+        eng.close()
+    assert merged["frag_ids"].shape[0] == got_all["frag_ids"].shape[0]
+    for k in merged:
+        assert np.array_equal(np.asarray(merged[k]), np.asarray(got_all[k])), k
