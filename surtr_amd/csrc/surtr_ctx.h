@@ -194,6 +194,8 @@ struct surtr_ctx
 {
     int device = 0;
     uint32_t n_wg_faces_alloc = 0;
+    // what the CUs can hold (surtr_create); max_wg* below are those, cut down to what the scratch of the current pieces leaves room for
+    uint32_t hw_wg = 512, hw_wg_faces = 1024, hw_wg_prep = 1792, hw_wg_big = 48, budget_vmax = 0xFFFFFFFFu, budget_hmax = 0xFFFFFFFFu;
     uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;
     ScratchPool pool_half{}; uint32_t n_wg_half = 0;       // k_clip_pairs_half: scratch for the half-size LDS topology only
     // Light pairs go to k_clip_pairs_half only when they are most of the event (small pieces: refracture).  Beside a
@@ -234,6 +236,9 @@ struct surtr_ctx
     ScratchPool pool{}; uint32_t n_wg = 0;
     ScratchPool pool_small{}; uint32_t n_wg_small = 0;      // one-wave kernels (Convex clip, refit)
     FaceScratch fs{}; uint2* d_blk = nullptr; uint32_t blk_per_wg = 0;
+    // second tier of k_faces scratch (pieces of more than SURTR_FACES_TIER half-edges): a few workgroups with room for a fragment
+    // as large as the largest piece; the first launch hands them the fragments that do not fit its own (d_face_list)
+    FaceScratch fs_big{}; uint2* d_blk_big = nullptr; uint32_t blk_per_wg_big = 0, n_wg_faces_big = 0; uint32_t* d_face_list = nullptr;
     Arena arena{};
     PairRec* d_pairs = nullptr; uint32_t cap_pairs = 0;
     FragRec* d_frags = nullptr; uint32_t cap_frags = 0;

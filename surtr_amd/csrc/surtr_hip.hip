@@ -711,7 +711,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                          uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
@@ -829,6 +829,10 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             if (fmt == IMG_NONE) cls = 13u;
             else if (fmt == IMG_NARROW)
                 cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
+            // k_clip_pairs_big has a few dozen workgroups: on a mesh whose bands outgrow the regular topology as a rule (some
+            // 100 000 vertices) it takes the first `big_quota` such pairs and the regular kernel's workgroups do the others on
+            // their global scratch (class 13), all of them at once instead of a queue behind 48
+            if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
             if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
@@ -846,12 +850,12 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on);
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -862,12 +866,12 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on);
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -1544,7 +1548,8 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                                                     FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
                                                     Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags,
                                                     uint32_t fan, uint32_t* __restrict__ face_n, uint32_t* __restrict__ face_off,
-                                                    int32_t* __restrict__ face_idx, uint32_t* __restrict__ frag_status)
+                                                    int32_t* __restrict__ face_idx, uint32_t* __restrict__ frag_status,
+                                                    const uint32_t* __restrict__ take_list, uint32_t* __restrict__ push_list)
 {
     __shared__ Shared sh;
     // staging of a small fragment for the serial ExtractFaces (see "irregular" below)
@@ -1575,7 +1580,11 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
     while (true)
     {
         __syncthreads();
-        if (tid == 0) sh.misc[7] = frag_of_ticket(A, forder, cap_frags, atomicAdd(&A.cursors[7], 1u));
+        if (tid == 0)
+        {
+            if (take_list == nullptr) sh.misc[7] = frag_of_ticket(A, forder, cap_frags, atomicAdd(&A.cursors[7], 1u));
+            else { const uint32_t t = atomicAdd(&A.cursors[86], 1u); sh.misc[7] = t < A.cursors[85] ? take_list[t] : 0xFFFFFFFFu; }      // second tier: the list of the first
+        }
         __syncthreads();
         const uint32_t f = sh.misc[7];
         if (f >= nf) break;
@@ -1586,7 +1595,15 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         const unsigned long long frag_t0 = __builtin_readcyclecounter();
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
 #endif
-        if (H > HF) { if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY); continue; }
+        if (H > HF)
+        {
+            if (tid == 0)
+            {
+                if (push_list != nullptr) push_list[atomicAdd(&A.cursors[85], 1u)] = f;      // a fragment for the second tier's scratch
+                else atomicMax(&A.cursors[5], (uint32_t)SURTR_E_CAPACITY);
+            }
+            continue;
+        }
         const float* pos = A.pos + 3 * (size_t)fr.mv_off;
         const uint32_t* loff = A.loff + fr.mv_off; const uint32_t* llen = A.llen + fr.mv_off;
         const int32_t* nbr = A.nbr + fr.mh_off;           // ring of v starts at loff[v]-mh_off
@@ -2218,6 +2235,7 @@ int surtr_create(int device, surtr_ctx** out)
             if (const char* e = getenv("SURTR_PREP_PER_CU")) { const int v = atoi(e); if (v > 0 && v <= 32) prep_per_cu = (uint32_t)v; }
             ctx->max_wg_prep = (uint32_t)prop.multiProcessorCount * prep_per_cu;
         }
+        ctx->hw_wg = ctx->max_wg; ctx->hw_wg_faces = ctx->max_wg_faces; ctx->hw_wg_prep = ctx->max_wg_prep; ctx->hw_wg_big = ctx->n_wg_big;
     }
     // (surtr_destroy releases whatever was created so far: no leak on a failure half-way)
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess ||
@@ -2240,6 +2258,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->d_upload_err); free_dev(ctx->d_group_xf); free_dev(ctx->d_world); free_dev(ctx->sort_tmp); free_dev(ctx->d_from);
     free_dev(ctx->d_v012); free_dev(ctx->d_planes); free_dev(ctx->d_plane_off);
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
+    free_dev(ctx->fs_big.base); free_dev(ctx->d_blk_big); free_dev(ctx->d_face_list);
     free_dev(ctx->d_pair_order); free_dev(ctx->d_face_group);
     free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
@@ -2351,29 +2370,75 @@ int surtr_upload_planes(surtr_ctx* ctx, uint32_t n_cells, const uint32_t* plane_
     return SURTR_OK;
 }
 
+// Per-workgroup scratch grows with the largest piece (the wide variant of the clip holds a whole band with all its cuts, a
+// k_faces workgroup the loops of a whole fragment).  With pieces of a few 100 000 vertices the full complement of workgroups
+// would not fit in HBM: the persistent kernels then run with as many workgroups as a fixed share of the memory holds (a
+// quarter for the clip, an eighth for k_faces, a sixteenth for the pre-pass) -- slower, not out of memory.  configs[3] needs
+// 8 GB + 22 GB + 0.8 GB at full size on a 288 GB part and is not affected.
+#define SURTR_FACES_TIER_DEFAULT 524288u      // half-edges of a fragment the regular k_faces workgroups have room for (25 MB each)
+static void budget_workgroups(surtr_ctx* ctx)
+{
+    if (ctx->budget_vmax == ctx->vmax && ctx->budget_hmax == ctx->hmax) return;
+    ctx->budget_vmax = ctx->vmax; ctx->budget_hmax = ctx->hmax;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) total_b = (size_t)64 << 30;
+    if (const char* e = getenv("SURTR_MEM_BUDGET_MB")) { const long v = atol(e); if (v > 0) total_b = (size_t)v << 20; }
+    auto fit = [](size_t budget, size_t per, uint32_t lo, uint32_t hi) {
+        const size_t n = per ? budget / per : hi;
+        return (uint32_t)std::min<size_t>(hi, std::max<size_t>(lo, n));
+    };
+    const uint32_t CV = ctx->user_cv ? ctx->user_cv : 2 * ctx->vmax + 4096, CH = ctx->user_ch ? ctx->user_ch : 3 * ctx->hmax + 16384;
+    const uint32_t all = fit(total_b / 4, scratch_bytes_per_wg(std::max(CV, 64u), CH, ctx->vmax), 20u, ctx->hw_wg + ctx->hw_wg_big);
+    ctx->n_wg_big = all >= ctx->hw_wg + ctx->hw_wg_big ? ctx->hw_wg_big : std::min(ctx->hw_wg_big, std::max(4u, all / 8u));
+    ctx->max_wg = std::min(ctx->hw_wg, all - ctx->n_wg_big);
+    size_t HF = (size_t)ctx->hmax + ctx->hmax / 2 + 8192;
+    {
+        size_t tier = SURTR_FACES_TIER_DEFAULT;
+        if (const char* e = getenv("SURTR_FACES_TIER_HE")) { const long v = atol(e); if (v >= 64) tier = (size_t)v; }
+        HF = std::min(HF, tier);      // larger fragments go to the second tier of k_faces (ensure_scratch)
+    }
+    ctx->max_wg_faces = fit(total_b / 8, HF * 48, 16u, ctx->hw_wg_faces);
+    ctx->max_wg_prep = fit(total_b / 16, prep_bytes_per_wg(std::max(ctx->vmax, 64u)), 16u, ctx->hw_wg_prep);
+}
+
 static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint32_t n_wg)
 {
-    uint32_t n_wg_faces = std::max(n_wg, ctx->max_wg_faces);
+    uint32_t n_wg_faces = std::max(1u, ctx->max_wg_faces);
     if (const char* e = getenv("SURTR_FACES_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > n_wg_faces && v <= 8192u) n_wg_faces = v; }
-    ctx->n_wg_faces_alloc = n_wg_faces;
     // Tombstones keep every vertex ever created in its slot, so the wide (global) variant is sized for
     // the band plus all cuts; the LDS variant has fixed capacities (SURTR_LV / SURTR_LH).
     uint32_t CV = ctx->user_cv ? ctx->user_cv : 2 * need_v + 4096;
     uint32_t CH = ctx->user_ch ? ctx->user_ch : 3 * need_h + 16384;
     if (CV < 64) CV = 64;
     const uint32_t VMAX = need_v;
-    if (ctx->pool.base && ctx->pool.CV >= CV && ctx->pool.CH >= CH && ctx->pool.VMAX >= VMAX && ctx->n_wg >= n_wg) return SURTR_OK;
+    if (ctx->pool.base && ctx->pool.CV >= CV && ctx->pool.CH >= CH && ctx->pool.VMAX >= VMAX && ctx->n_wg >= n_wg && ctx->n_wg_faces_alloc >= n_wg_faces) return SURTR_OK;
+    ctx->n_wg_faces_alloc = n_wg_faces;
     free_dev(ctx->pool.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     ctx->pool.base = nullptr; ctx->fs.base = nullptr; ctx->d_blk = nullptr;
     ctx->pool.CV = CV; ctx->pool.CH = CH; ctx->pool.VMAX = VMAX;
     ctx->pool.per_wg = scratch_bytes_per_wg(CV, CH, VMAX);
     ctx->n_wg = n_wg;
     HIPCHK(hipMalloc((void**)&ctx->pool.base, ctx->pool.per_wg * n_wg));
-    ctx->fs.HF = need_h + need_h / 2 + 8192;
+    const uint32_t HF_full = need_h + need_h / 2 + 8192;
+    uint32_t tier = SURTR_FACES_TIER_DEFAULT;
+    if (const char* e = getenv("SURTR_FACES_TIER_HE")) { const long v = atol(e); if (v >= 64) tier = (uint32_t)v; }
+    ctx->fs.HF = std::min(HF_full, tier);
     ctx->fs.per_wg = (size_t)12 * ctx->fs.HF;
     HIPCHK(hipMalloc((void**)&ctx->fs.base, ctx->fs.per_wg * 4 * n_wg_faces));
     ctx->blk_per_wg = ctx->fs.HF / SURTR_LANES + 4;
     HIPCHK(hipMalloc((void**)&ctx->d_blk, (size_t)ctx->blk_per_wg * 8 * n_wg_faces));
+    free_dev(ctx->fs_big.base); free_dev(ctx->d_blk_big); ctx->fs_big.base = nullptr; ctx->d_blk_big = nullptr; ctx->n_wg_faces_big = 0;
+    if (HF_full > ctx->fs.HF)
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) total_b = (size_t)64 << 30;
+        if (const char* e = getenv("SURTR_MEM_BUDGET_MB")) { const long v = atol(e); if (v > 0) total_b = (size_t)v << 20; }
+        ctx->fs_big.HF = HF_full; ctx->fs_big.per_wg = (size_t)12 * HF_full;
+        ctx->n_wg_faces_big = (uint32_t)std::min<size_t>(64, std::max<size_t>(2, (total_b / 16) / (ctx->fs_big.per_wg * 4)));
+        HIPCHK(hipMalloc((void**)&ctx->fs_big.base, ctx->fs_big.per_wg * 4 * ctx->n_wg_faces_big));
+        ctx->blk_per_wg_big = HF_full / SURTR_LANES + 4;
+        HIPCHK(hipMalloc((void**)&ctx->d_blk_big, (size_t)ctx->blk_per_wg_big * 8 * ctx->n_wg_faces_big));
+    }
     return SURTR_OK;
 }
 
@@ -2464,12 +2529,14 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs, uint64_t min_v = 0, ui
         if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_frags, (size_t)capIsl * sizeof(FragRec));
         if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_forder, (size_t)capIsl * 16 * 4);
         if (e == hipSuccess) e = hipMalloc((void**)&ctx->d_frag_status, (size_t)capIsl * 4);
+        if (e == hipSuccess) { free_dev(ctx->d_face_list); ctx->d_face_list = nullptr; e = hipMalloc((void**)&ctx->d_face_list, (size_t)capIsl * 4); }
         if (e != hipSuccess)
         {
             // out of memory half-way: leave no buffer behind, so that a later, smaller event allocates afresh
             free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
             free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->d_frags); free_dev(ctx->d_forder); free_dev(ctx->d_frag_status);
             ctx->d_frag_status = nullptr;
+            free_dev(ctx->d_face_list); ctx->d_face_list = nullptr;
             ctx->arena.pos = nullptr; ctx->arena.loff = nullptr; ctx->arena.llen = nullptr; ctx->arena.nbr = nullptr;
             ctx->arena.idx = nullptr; ctx->arena.isl = nullptr; ctx->d_frags = nullptr; ctx->d_forder = nullptr;
             ctx->err = std::string("arena allocation: ") + hipGetErrorString(e);
@@ -2512,10 +2579,11 @@ static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pai
 static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
     (void)hipSetDevice(ctx->device);
+    budget_workgroups(ctx);
     const uint32_t max_wg = ctx->max_wg;
     const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
     // scratch slots [0, max_wg) belong to k_clip_pairs, the n_wg_big after them to k_clip_pairs_big
-    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, std::max(max_wg + ctx->n_wg_big, ctx->n_wg));
+    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, max_wg + ctx->n_wg_big);
     if (rc) return rc;
     const uint32_t n_wg_small = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_small));
     rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
@@ -2576,11 +2644,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, 2u * ctx->n_wg_big);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, 2u * ctx->n_wg_big);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
@@ -2641,14 +2709,19 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (flags & SURTR_EVT_RENDER)
     {
         PROF_BEGIN(3);
-        uint32_t g_faces = std::max(n_wg, ctx->max_wg_faces), t_faces = SURTR_WG;
+        uint32_t g_faces = std::max(1u, ctx->max_wg_faces), t_faces = SURTR_WG;
         if (both) g_faces = std::max(1u, ctx->max_wg_faces / 2u);
         if (both) if (const char* e = getenv("SURTR_FACES_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_faces_alloc) g_faces = v; }
         if (const char* e = getenv("SURTR_FACES_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_faces_alloc) g_faces = v; }
         if (const char* e = getenv("SURTR_FACES_THREADS")) { const uint32_t v = (uint32_t)atoi(e); if (v == 64 || v == 128 || v == 256) t_faces = v; }
+        const bool tiers = ctx->n_wg_faces_big != 0;
         hipLaunchKernelGGL(k_faces, dim3(g_faces), dim3(t_faces), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
                            ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
-                           ctx->d_frag_status);
+                           ctx->d_frag_status, (const uint32_t*)nullptr, tiers ? ctx->d_face_list : (uint32_t*)nullptr);
+        if (tiers)      // the fragments too large for the scratch of those workgroups
+            hipLaunchKernelGGL(k_faces, dim3(ctx->n_wg_faces_big), dim3(t_faces), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs_big, ctx->d_blk_big,
+                               ctx->blk_per_wg_big, ctx->arena, ctx->d_forder, ctx->cap_frags, 0u, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr,
+                               ctx->d_frag_status, (const uint32_t*)ctx->d_face_list, (uint32_t*)nullptr);
         PROF_END(3);
     }
     if (both)
@@ -2778,8 +2851,15 @@ static int launch_faces(surtr_ctx* ctx, uint32_t fan, uint32_t* d_face_n, uint32
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 14, 0, 4, st));
     HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
     PROF_BEGIN(3);
+    const bool tiers = ctx->n_wg_faces_big != 0;
+    if (tiers) HIPCHK(hipMemsetAsync(ctx->arena.cursors + 85, 0, 8, st));      // the second tier's list: fragments pushed (85), tickets taken (86)
     hipLaunchKernelGGL(k_faces, dim3(std::max(1u, ctx->max_wg_faces)), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs, ctx->d_blk,
-                       ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, fan, d_face_n, d_face_off, d_face_idx, ctx->d_frag_status);
+                       ctx->blk_per_wg, ctx->arena, ctx->d_forder, ctx->cap_frags, fan, d_face_n, d_face_off, d_face_idx, ctx->d_frag_status,
+                       (const uint32_t*)nullptr, tiers ? ctx->d_face_list : (uint32_t*)nullptr);
+    if (tiers)
+        hipLaunchKernelGGL(k_faces, dim3(ctx->n_wg_faces_big), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_counts, ctx->fs_big, ctx->d_blk_big,
+                           ctx->blk_per_wg_big, ctx->arena, ctx->d_forder, ctx->cap_frags, fan, d_face_n, d_face_off, d_face_idx, ctx->d_frag_status,
+                           (const uint32_t*)ctx->d_face_list, (uint32_t*)nullptr);
     PROF_END(3);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
@@ -2904,7 +2984,7 @@ int surtr_extract_faces(surtr_ctx* ctx, uint32_t nv, const float* pos, const uin
     uint32_t *d_n = nullptr, *d_off = nullptr; int32_t* d_idx = nullptr;
     auto cleanup = [&]() { free_dev(d_n); free_dev(d_off); free_dev(d_idx); };
     if (hipMalloc((void**)&d_n, 16) != hipSuccess || hipMalloc((void**)&d_off, ((size_t)H + 2) * 4) != hipSuccess ||
-        hipMalloc((void**)&d_idx, ((size_t)ctx->fs.HF + 2) * 4) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
+        hipMalloc((void**)&d_idx, ((size_t)std::max(ctx->fs.HF, ctx->fs_big.base ? ctx->fs_big.HF : 0u) + 2) * 4) != hipSuccess) { cleanup(); return SURTR_E_HIP; }
     (void)hipMemsetAsync(d_n, 0, 16, ctx->stream);
     rc = launch_faces(ctx, 0u, d_n, d_off, d_idx);
     surtr_counts c;

@@ -412,3 +412,23 @@ def test_deep_lobed_mesh_emulated(emul_engine, oracle):
     c, got, ref = run_event(emul_engine, oracle, scenes.urchin_scene(64))
     assert c.status == 0 and int(got["frag_ids"][:, 2].max()) >= 1
     assert_event_equal(got, ref)
+
+
+def test_faces_second_tier_and_workgroup_budget(emul_engine, oracle, monkeypatch):
+    """Pieces of some 100 000 vertices: the regular k_faces workgroups get scratch for fragments of up to 2^19 half-edges and
+    hand larger ones to a second launch with full-size scratch; the persistent kernels run with as many workgroups as a share
+    of the device memory holds.  Forced here with a 256-half-edge tier and a 64 MB "device": same event."""
+    monkeypatch.setenv("SURTR_FACES_TIER_HE", "256")
+    monkeypatch.setenv("SURTR_MEM_BUDGET_MB", "64")
+    c, got, ref = run_event(emul_engine, oracle, scenes.blob_scene(64), 3)
+    assert c.status == 0 and c.n_frag == ref["frag_ids"].shape[0] > 40
+    assert_event_equal(got, ref)
+    eng = emul_engine.Engine(0)
+    try:
+        # the single-solid face extraction goes through the same two launches
+        sc = scenes.blob_scene(8)
+        fo, fi = eng.extract_faces(sc["mesh"])
+        rfo, rfi = oracle.extract_faces(sc["mesh"])
+        assert np.array_equal(fo, rfo) and np.array_equal(fi, rfi)
+    finally:
+        eng.close()
