@@ -2636,6 +2636,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order);
     PROF_END(6);
+    uint32_t big_quota = 2u * ctx->n_wg_big;
+    if (const char* e = getenv("SURTR_BIG_QUOTA")) big_quota = (uint32_t)atoi(e);      // (tests: 0 sends every big band to the regular kernel's global scratch)
     PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
     uint32_t wide_max = 4u * ctx->max_wg;
@@ -2644,11 +2646,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, 2u * ctx->n_wg_big);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, 2u * ctx->n_wg_big);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
