@@ -1375,7 +1375,9 @@ __device__ __forceinline__ bool on_right(const float* a, const float* b, const f
 
 // Poly::EarClipping (Src/Poly.cpp:764-913) for one face, one lane.  loop = vertex ids of the face;
 // tmp = 3*N ints (prev, next, reflex).  Writes vertex ids (3 per triangle) to out; returns the count.
-__device__ static uint32_t ear_clip_face(const float* pos, const int32_t* loop, int N, int32_t* tmp, uint32_t* out)
+// pos / loop may be global or LDS (k_faces stages small fragments): always inlined, so that the compiler sees which.
+template <class LP>
+__device__ __attribute__((always_inline)) static inline uint32_t ear_clip_face(const float* pos, const LP* loop, int N, int32_t* tmp, uint32_t* out)
 {
     if (N <= 2) return 0;
     if (N == 3) { out[0] = loop[0]; out[1] = loop[1]; out[2] = loop[2]; return 3; }
@@ -1442,16 +1444,90 @@ __device__ static uint32_t ear_clip_face(const float* pos, const int32_t* loop, 
     return at + 3;
 }
 
+// The same for a face of at most 8 vertices (the quads, in practice: 5..64-gons go to the wave version) with prev / next /
+// reflex packed into registers instead of a scratch array in global memory.  Same traversal, same triangles.
+template <class LP>
+__device__ __attribute__((always_inline)) static inline uint32_t ear_clip_small(const float* pos, const LP* loop, int N, uint32_t* out)
+{
+    if (N <= 2) return 0;
+    if (N == 3) { out[0] = loop[0]; out[1] = loop[1]; out[2] = loop[2]; return 3; }
+    auto P = [&](int i) -> const float* { return pos + 3 * (int)loop[i]; };
+    const float* A0 = P(0); const float* B0 = P(1); const float* C0 = P(2);
+    float nx, ny, nz;
+    {
+        const float ux = B0[0] - A0[0], uy = B0[1] - A0[1], uz = B0[2] - A0[2];
+        const float wx = C0[0] - A0[0], wy = C0[1] - A0[1], wz = C0[2] - A0[2];
+        nx = uy * wz - uz * wy; ny = uz * wx - ux * wz; nz = ux * wy - uy * wx;
+    }
+    {   // IsCCW (:753-762)
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int v = 0; v < N; ++v)
+        {
+            const float* p = P(v); const float* q = P((v + 1) % N);
+            const float ux = p[0] - A0[0], uy = p[1] - A0[1], uz = p[2] - A0[2];
+            const float wx = q[0] - A0[0], wy = q[1] - A0[1], wz = q[2] - A0[2];
+            sx = sx + (uy * wz - uz * wy); sy = sy + (uz * wx - ux * wz); sz = sz + (ux * wy - uy * wx);
+        }
+        if (dot3(sx, sy, sz, nx, ny, nz) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    }
+    uint32_t prv = 0, nxt = 0, rfx = 0;                        // 4 bits per vertex / 1 bit per vertex
+    auto get = [](uint32_t w, int i) -> int { return (int)((w >> (4 * i)) & 15u); };
+    auto put = [](uint32_t& w, int i, int v) { w = (w & ~(15u << (4 * i))) | ((uint32_t)v << (4 * i)); };
+    for (int i = 0; i < N; ++i) { put(prv, i, (i + N - 1) % N); put(nxt, i, (i + 1) % N); }
+    for (int i = 0; i < N; ++i)
+        if (!on_right(P(get(prv, i)), P(i), P(get(nxt, i)), nx, ny, nz)) rfx |= 1u << i;
+    int skipped = 0, left = N, cur = 0;
+    uint32_t at = 0;
+    while (left > 3)
+    {
+        const int p = get(prv, cur), n = get(nxt, cur);
+        bool ear = ((rfx >> cur) & 1u) == 0u;
+        if (ear)
+        {
+            const float* a = P(p); const float* b = P(cur); const float* c = P(n);
+            for (int r = 0; r < N && ear; ++r)
+            {
+                if (!((rfx >> r) & 1u)) continue;              // reflexVertices, in index order
+                if (r == p || r == n) continue;
+                const float* q = P(r);
+                if ((q[0] == a[0] && q[1] == a[1] && q[2] == a[2]) || (q[0] == b[0] && q[1] == b[1] && q[2] == b[2])) continue;
+                if (!on_right(a, b, q, nx, ny, nz)) continue;
+                if (!on_right(b, c, q, nx, ny, nz)) continue;
+                if (!on_right(c, a, q, nx, ny, nz)) continue;
+                ear = false;
+            }
+        }
+        if (ear)
+        {
+            out[at] = loop[p]; out[at + 1] = loop[cur]; out[at + 2] = loop[n];
+            put(nxt, p, n); put(prv, n, p);
+            const int adj[2] = {p, n};
+            for (int k = 0; k < 2; ++k)
+            {
+                const int v = adj[k];
+                if (!((rfx >> v) & 1u)) continue;
+                if (on_right(P(get(prv, v)), P(v), P(get(nxt, v)), nx, ny, nz)) rfx &= ~(1u << v);
+            }
+            at += 3; --left; skipped = 0;
+        }
+        else if (++skipped > left) return 0;             // stalled: the face is dropped (:899-903)
+        cur = n;
+    }
+    out[at] = loop[get(prv, cur)]; out[at + 1] = loop[cur]; out[at + 2] = loop[get(nxt, cur)];
+    return at + 3;
+}
+
 #if SURTR_LANES == 64
 // Poly::EarClipping for one face of 5..64 vertices on one wave: lane i holds vertex i (position, prev/next
 // link, reflex flag) in registers; the sequential ear loop (:868-906) runs wave-uniformly, and the scan of the
 // reflex list (:837-856, an "any reflex vertex inside the candidate ear") is one ballot.  Same triangles, same
 // order, same stall rule as ear_clip_face.
-__device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* loop, int N, uint32_t* out)
+template <class LP>
+__device__ __attribute__((always_inline)) static inline uint32_t ear_clip_face_wave(const float* pos, const LP* loop, int N, uint32_t* out)
 {
     const int lane = (int)lane_id();
     const bool mine = lane < N;
-    const int32_t vid = loop[mine ? lane : 0];
+    const int32_t vid = (int32_t)loop[mine ? lane : 0];
     const float x = pos[3 * vid], y = pos[3 * vid + 1], z = pos[3 * vid + 2];
     // (every index below is wave-uniform: broadcasts go through scalar registers, not the LDS crossbar)
 #ifdef SURTR_EAR_SHFL
@@ -1544,7 +1620,7 @@ __device__ static uint32_t ear_clip_face_wave(const float* pos, const int32_t* l
 // fan != 0: RenderPolyhedron's isConvex branch (triangle fan per face, Src/Poly.cpp:696-706) instead of EarClipping.
 // face_n / face_off / face_idx (nullptr in an event): the face loops of Poly::ExtractFaces for the single-solid operators
 // (surtr_extract_faces: one fragment loaded); face_n = {faces, loop entries}.
-__global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_faces(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     FaceScratch FS, uint2* __restrict__ blkpool, uint32_t blk_per_wg,
                                                     Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags,
                                                     uint32_t fan, uint32_t* __restrict__ face_n, uint32_t* __restrict__ face_off,
@@ -1562,7 +1638,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
     // the sliver path's visit marks, or (regular fragments of at most FL_J half-edges) the pointer-jumping arrays
     struct IrrLds { uint8_t vis[FL_H]; uint32_t cov[FL_H]; };
     struct JumpLds { uint16_t k0[FL_J], k1[FL_J], x0[FL_J], x1[FL_J]; };
-    union FacesLds { IrrLds irr; JumpLds jmp; };
+    struct EarLds { float pos[3 * FL_V]; uint16_t loop[FL_J]; };       // once the faces are known: positions and face loops for the ear clippers
+    union FacesLds { IrrLds irr; JumpLds jmp; EarLds ear; };
+    static_assert(sizeof(EarLds) <= sizeof(IrrLds), "the ear staging reuses the bytes of the face search");
     __shared__ FacesLds FU;
     uint8_t* const f_vis = FU.irr.vis; uint32_t* const f_cov = FU.irr.cov;
     const uint32_t tid = threadIdx.x;
@@ -1910,7 +1988,16 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
         }
         STAMP(62);
         // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
-        //    room for 3*len indices at 3*lo
+        //    room for 3*len indices at 3*lo.  The arrays of the face search are dead now: a small fragment's positions and
+        //    loops go there, so that the ear tests read LDS instead of waiting for global memory vertex by vertex.
+        const bool ear_lds = !fan && n <= FL_V && lensum <= FL_J;
+        __syncthreads();
+        if (ear_lds)
+        {
+            for (uint32_t i = tid; i < 3u * n; i += group_size()) FU.ear.pos[i] = pos[i];
+            for (uint32_t e = tid; e < lensum; e += group_size()) FU.ear.loop[e] = (uint16_t)loopbuf[e];
+            __syncthreads();
+        }
         if (fan)
         {
             // isConvex: (f[0], f[v], f[v+1]) for v = 1 .. size-2 (Src/Poly.cpp:698-705)
@@ -1938,7 +2025,9 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
                 if (ord % group_waves() != wave_id()) continue;
                 const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                 const uint32_t lo = lane_bcast(mylo, src), len = lane_bcast(mylen, src);
-                const uint32_t cnt = ear_clip_face_wave(pos, loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
+                uint32_t cnt;
+                if (ear_lds) cnt = ear_clip_face_wave((const float*)FU.ear.pos, (const uint16_t*)FU.ear.loop + lo, (int)len, tri + 3u * (size_t)lo);
+                else cnt = ear_clip_face_wave(pos, (const int32_t*)loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
                 if (lane_id() == 0) fcnt[f0 + src] = cnt;
             }
         }
@@ -1952,7 +2041,12 @@ __global__ __launch_bounds__(SURTR_WG) void k_faces(FragRec* __restrict__ frags,
             if (len >= 5u && len <= 64u) continue;
 #endif
             uint32_t* out = tri + 3u * (size_t)lo;
-            fcnt[fi] = (len >= 3u) ? ear_clip_face(pos, loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out) : 0u;
+            uint32_t cnt = 0u;
+            if (len >= 3u && len <= 8u)
+                cnt = ear_lds ? ear_clip_small((const float*)FU.ear.pos, (const uint16_t*)FU.ear.loop + lo, (int)len, out)
+                              : ear_clip_small(pos, (const int32_t*)loopbuf + lo, (int)len, out);
+            else if (len > 8u) cnt = ear_clip_face(pos, (const int32_t*)loopbuf + lo, (int)len, eartmp + 3 * (size_t)lo, out);
+            fcnt[fi] = cnt;
 #ifdef SURTR_STAMP
             if (len > 64u) { atomicAdd(&g_stamp[66], 1ull); atomicAdd(&g_stamp[67], (unsigned long long)len); }
 #endif
