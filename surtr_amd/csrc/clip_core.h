@@ -186,6 +186,7 @@ struct Shared
     uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;
     uint32_t misc[8];
+    uint32_t cutmask[4];              // prepass_emit: bit k = plane k is the first clipping plane of some vertex of the reduced solid
 #ifdef SURTR_STAMP
     unsigned long long ph[16];        // per-pair phase cycles (diagnostic build)
 #endif
@@ -752,6 +753,7 @@ __device__ __attribute__((always_inline)) inline void prepass_emit(const SolidIn
                 if (c == 0) atomicAdd(&sh.nzero[k], 1u);
             }
             T.fc[id] = (uint8_t)f;
+            if (f < 128u) atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u));      // planes that clip something of the band (cost estimate)
         }
         const uint32_t deg = T.llen[id];
         const int32_t* r = in.nbr + in.loff[v];

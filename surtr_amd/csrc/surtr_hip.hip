@@ -812,7 +812,9 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             T.ring = (uint16_t*)(img + lay.ring); T.pos = (float*)(img + lay.pos);
             T.succ = T.pred = T.pcnt = T.aux0 = T.aux1 = T.aux2 = T.aux3 = nullptr; T.blk = nullptr;
             T.capV = n; T.capH = hsum; T.nS = T.nLive = T.hUsed = 0; T.kcur = T.n0cur = 0; T.zmode = false;
-            prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);      // also counts sh.nzero
+            if (tid < 4u) sh.cutmask[tid] = 0u;
+            __syncthreads();
+            prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);      // also counts sh.nzero, collects sh.cutmask
             STAMP(74);
             prepass_finish_hist(F, sh);
             uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* nz = (uint32_t*)(img + lay.nzero);
@@ -828,7 +830,14 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             uint32_t cls = 15u;
             if (fmt == IMG_NONE) cls = 13u;
             else if (fmt == IMG_NARROW)
-                cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (n / 384u < 12u ? n / 384u : 12u);
+            {
+                // cost of the clip = cutting planes x ~41 000 cycles + load / islands / copy ~25 cycles per vertex, in units of
+                // 110 000 cycles; the planes that clip an original vertex of the band are a lower bound of the cutting planes
+                const uint32_t ncut = (uint32_t)(__builtin_popcount(sh.cutmask[0]) + __builtin_popcount(sh.cutmask[1]) +
+                                                 __builtin_popcount(sh.cutmask[2]) + __builtin_popcount(sh.cutmask[3]));
+                const uint32_t cost = (41u * ncut + n / 40u) / 110u;
+                cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (cost < 11u ? cost : 11u);
+            }
             // k_clip_pairs_big has a few dozen workgroups: on a mesh whose bands outgrow the regular topology as a rule (some
             // 100 000 vertices) it takes the first `big_quota` such pairs and the regular kernel's workgroups do the others on
             // their global scratch (class 13), all of them at once instead of a queue behind 48
