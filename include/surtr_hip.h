@@ -60,8 +60,10 @@ typedef struct surtr_counts {
     uint32_t n_idx;        /* triangle indices (render buffers) */
     uint32_t n_pairs;      /* (cell, piece) pairs processed */
     uint32_t status;       /* device-side status word, SURTR_OK or an error code */
-    uint32_t n_failed;     /* fragments that got no triangles because Poly::ExtractFaces does not terminate on them
-                            * (Src/Poly.cpp:100-118); frag_status names them.  The event itself is SURTR_OK. */
+    uint32_t n_failed;     /* fragments on which a per-fragment task of the reference has no valid result: no triangles because
+                            * Poly::ExtractFaces does not terminate on them (Src/Poly.cpp:100-118), or the un-refitted Convex
+                            * because m_refittingTask's clip of it is no polyhedron (a one-way link, Src/Poly.cpp:484-493 through a
+                            * stale ID); frag_status names them.  The event itself is SURTR_OK. */
 } surtr_counts;
 
 /* Host-side view used by surtr_event_download: every pointer may be NULL to
@@ -79,7 +81,7 @@ typedef struct surtr_fragments {
     float* vnc;                 /* 9*mesh_verts: VertexNormalColor (Inc/Mesh.h:4-13) of every Mesh vertex */
     uint32_t* idx_off;          /* n_frag+1 */
     uint32_t* idx;              /* n_idx, fragment-local vertex indices (Src/Poly.cpp:708-713) */
-    uint32_t* frag_status;      /* n_frag: SURTR_OK, or SURTR_E_TOPOLOGY for a fragment without triangles (see n_failed) */
+    uint32_t* frag_status;      /* n_frag: SURTR_OK, or SURTR_E_TOPOLOGY for a fragment without triangles / with its Convex not refitted (see n_failed) */
 } surtr_fragments;
 
 /* ---- life cycle -------------------------------------------------------- */

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 from oracle import oracle as O
 from surtr_amd import engine as E, scenes as S, meshgen as G
-from helpers import assert_event_equal
+from helpers import assert_event_equal, assert_event_equal_flagged
 
 def random_scene(rng, eng=None):
     kind = rng.integers(0, 5)
@@ -74,7 +74,7 @@ def main():
         ref = O.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=bool(flags & 1), render=bool(flags & 2), threads=8)
         try:
             assert c.status == 0
-            assert_event_equal(got, ref, render=bool(flags & 2))
+            assert_event_equal_flagged(got, ref, render=bool(flags & 2))
             ok = True
         except AssertionError as e:
             ok = False; bad += 1

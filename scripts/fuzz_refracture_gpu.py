@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from oracle import oracle as O
 from surtr_amd import engine as E
-from helpers import assert_event_equal
+from helpers import assert_event_equal, assert_event_equal_flagged
 from test_refracture import _refracture, _links_symmetric
 from surtr_amd import scenes as S, meshgen as G
 
@@ -82,8 +82,8 @@ def main():
         try:
             c, got, ref, npieces = _refracture(E, O, n_first, n_second, nu, nv)
             assert c.status == 0
-            assert_event_equal(got, ref)
-            res = "ok"
+            assert_event_equal_flagged(got, ref)      # (a flagged fragment: the reference's own result for it must be invalid)
+            res = "ok" if c.n_failed == 0 else "ok (%d fragment(s) flagged: no valid result in the reference)" % c.n_failed
         except AssertionError as e:
             res = "MISMATCH %s" % (e,); bad += 1
         except E.SurtrError as e:

@@ -118,7 +118,10 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
             for (uint32_t j = 0; j < deg; ++j)
             {
                 const int32_t jn = S.ring[i * LIT_STRIDE + j];
-                if (!ok(jn, n1)) return SURTR_E_TOPOLOGY;                        // (an insertion moved a removal mark here: the reference reads comp[-1])
+                // a removal mark that an insertion moved up into the part of the ring still to be visited: the reference reads
+                // comp[-1] there -- the word in front of its vertex array, which is not -1 -- and goes on
+                if (jn == -1) continue;
+                if (!ok(jn, n1)) return SURTR_E_TOPOLOGY;
                 if (S.comp[jn] != -1) continue;
                 int32_t prev = (int32_t)i, cur = jn; uint32_t steps = 0;
                 while (S.comp[cur] == -1 && steps++ < n1)                        // :389-394

@@ -1179,7 +1179,8 @@ __device__ __forceinline__ float hull_vol(const float* a, const float* b, const 
 }
 
 __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
-                                                    ScratchPool pool, Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags)
+                                                    ScratchPool pool, Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags,
+                                                    uint32_t* __restrict__ frag_status)
 {
     __shared__ Shared sh;
     __shared__ ArgF slotF[SURTR_NWAVE];
@@ -1352,7 +1353,14 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             // field-wise: k_faces updates other fields of the same record at the same time
             frags[f].cv_off = nvoff; frags[f].cv_n = ncn; frags[f].ch_off = nhoff; frags[f].ch_n = nchn;
         }
-        if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
+        if (err == SURTR_E_TOPOLOGY && frag_status != nullptr)
+        {
+            // Where the reference's own clip of this Convex by the slabs is no polyhedron any more (a link to a clipped vertex
+            // that survives, renumbered through a stale ID), the fragment keeps the Convex it had -- a superset of the refitted
+            // one -- and is flagged; the event and the other fragments stand (as for a fragment without triangles in k_faces).
+            if (tid == 0 && atomicExch(&frag_status[f], (uint32_t)SURTR_E_TOPOLOGY) == 0u) atomicAdd(&A.cursors[14], 1u);
+        }
+        else if (err != 0 && tid == 0) atomicMax(&A.cursors[5], (uint32_t)err);
 #ifdef SURTR_STAMP
         if (tid == 0)
         {
@@ -1984,8 +1992,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
             if (tid == 0)
             {
                 frags[f].idx_off = 0; frags[f].idx_n = 0;
-                if (frag_status != nullptr) frag_status[f] = SURTR_E_TOPOLOGY;
-                atomicAdd(&A.cursors[14], 1u);
+                // (k_refit, beside this kernel, may flag the same fragment: it is counted once)
+                if (frag_status == nullptr || atomicExch(&frag_status[f], (uint32_t)SURTR_E_TOPOLOGY) == 0u) atomicAdd(&A.cursors[14], 1u);
             }
             continue;
         }
@@ -2808,7 +2816,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         uint32_t g_refit = ctx->n_wg_small;
         if (both) g_refit = std::min(g_refit, ctx->max_wg_faces / 4u * 5u);
         if (both) if (const char* e = getenv("SURTR_REFIT_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_small) g_refit = v; }
-        hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
+        hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status);
         PROF_END_ON(2, st_refit);
     }
     if (flags & SURTR_EVT_RENDER)
@@ -2938,7 +2946,7 @@ int surtr_event_refit(surtr_ctx* ctx)
     // k_refit pulls fragments from work queue 6
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 6, 0, 4, st));
     PROF_BEGIN(2);
-    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags);
+    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status);
     PROF_END(2);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
@@ -2953,8 +2961,11 @@ static int launch_faces(surtr_ctx* ctx, uint32_t fan, uint32_t* d_face_n, uint32
     // queue 7 = fragments for k_faces, cursor 2 = index arena, 14 = fragments without triangles
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 7, 0, 4, st));
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 2, 0, 4, st));
-    HIPCHK(hipMemsetAsync(ctx->arena.cursors + 14, 0, 4, st));
-    HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
+    if (!(ctx->last_flags & SURTR_EVT_REFIT))      // (a refit of these fragments may have flagged some: those flags stay)
+    {
+        HIPCHK(hipMemsetAsync(ctx->arena.cursors + 14, 0, 4, st));
+        HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
+    }
     PROF_BEGIN(3);
     const bool tiers = ctx->n_wg_faces_big != 0;
     if (tiers) HIPCHK(hipMemsetAsync(ctx->arena.cursors + 85, 0, 8, st));      // the second tier's list: fragments pushed (85), tickets taken (86)
@@ -3070,6 +3081,11 @@ int surtr_refit_solid(surtr_ctx* ctx, uint32_t mnv, const float* mpos, const uin
     surtr_counts c;
     rc = surtr_event_counts(ctx, &c);
     if (rc) return rc;
+    if (c.n_failed != 0)      // one solid was asked for: the reference's clip of it by the slabs is no polyhedron
+    {
+        ctx->err = "refit: the reference's result for this solid is not a polyhedron";
+        return SURTR_E_TOPOLOGY;
+    }
     if (out_nv) *out_nv = c.conv_verts;
     if (out_nh) *out_nh = c.conv_nbrs;
     if (!out_pos && !out_off && !out_nbr) return SURTR_OK;

@@ -54,6 +54,7 @@ template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 static inline bool __all(bool p) { return p; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline int __builtin_amdgcn_readlane(int v, int) { return v; }
 static inline int __builtin_amdgcn_update_dpp(int old, int, int, int, int, bool) { return old; }      // lane 0 never has a source lane

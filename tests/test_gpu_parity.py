@@ -486,6 +486,19 @@ def test_degenerate_walk_bound_pair(gpu_engine, oracle):
     assert_event_equal(got, ref)
 
 
+def test_refit_invalid_in_reference_is_isolated(gpu_engine, oracle):
+    """Refracture fuzz seed 555002, case 82: one fragment's refit has no valid result in the reference (a one-way link);
+    the single fragment first (tests/test_emul_parity.py), then the whole event (200 first-level cells of a 53 x 25 torus,
+    17 cells per piece): SURTR_OK, one flagged fragment with its Convex kept, everything else equal."""
+    import test_emul_parity as _ep
+    from helpers import assert_event_equal_flagged
+    from test_refracture import _refracture
+    _ep.check_refit_invalid_in_reference(gpu_engine, oracle)
+    c, got, ref, npieces = _refracture(gpu_engine, oracle, 200, 17, 53, 25)
+    assert c.status == 0 and c.n_failed == 1 and int((got["frag_status"] != 0).sum()) == 1
+    assert_event_equal_flagged(got, ref)
+
+
 @pytest.mark.parametrize("name,n", [("urchin64", 64), ("urchin1024", 1024)])
 def test_deep_lobed_mesh_islands(gpu_engine, oracle, name, n):
     """cfg2 / cfg3 cell counts on the deep-lobed mesh (meshgen.urchin): at least a tenth of the non-empty cells hold two or
