@@ -7,9 +7,10 @@
 // order-free formulation follows.  Mostly the solid is gone a moment later (fewer than four vertices left, :497-499) and the
 // reference's answer is simply "empty".  This file is the last resort for such a solid when it is small: the whole clip again,
 // literally (bounding-box shortcut, snapshot of the rings, insertions, two-neighbour collapse, compaction), with fixed-stride
-// rings in the workgroup's global scratch.  Where the reference itself leaves its domain -- an index out of range, or a link
-// to a clipped vertex that survives the compaction of a solid that stays (it would be renumbered through a stale ID) -- it
-// returns SURTR_E_TOPOLOGY, as before.  Found by scripts/fuzz_refracture_gpu.py, seed 555 case 110
+// rings in the workgroup's global scratch.  Where the reference itself leaves its domain -- an index that is no vertex: out of
+// range, or a link to a clipped vertex that survives the compaction and is renumbered through an ID that was never set -- it
+// returns SURTR_E_TOPOLOGY, as before; a surviving link renumbered through a stale but valid ID is carried on like the reference
+// does (the result is the reference's, and no polyhedron: `stale_out` says so).  Found by scripts/fuzz_refracture_gpu.py, seed 555 case 110
 // (tests/golden/degenerate_walk_bound_convex.npz).
 #pragma once
 #include "clip_core.h"
@@ -47,9 +48,10 @@ __device__ inline int lit_box_side(const float4 pl, const double lo[3], const do
 
 // One lane.  Returns 0 (n_out vertices left in S, compacted: rings of vertex v = S.ring[v * LIT_STRIDE ..], S.len[v] entries),
 // SURTR_E_TOPOLOGY where the reference leaves its domain, SURTR_E_CAPACITY when the solid does not fit.
-__device__ inline int literal_clip(const SolidIn in, const uint32_t F, const float4* planes, LitSolid S, uint32_t* n_out)
+__device__ inline int literal_clip(const SolidIn in, const uint32_t F, const float4* planes, LitSolid S, uint32_t* n_out, bool* stale_out = nullptr)
 {
     uint32_t n = in.nv;
+    bool stale = false;
     if (n > S.capV) return SURTR_E_CAPACITY;
     for (uint32_t v = 0; v < n; ++v)
     {
@@ -178,7 +180,7 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
         for (int a = 0; a < 3; ++a) { lo[a] = 1.7976931348623157e308; hi[a] = -1.7976931348623157e308; }
         uint32_t live = 0;
         for (uint32_t i = 0; i < n1; ++i) if (S.comp[i] >= 0) { S.id[i] = (int32_t)live++; grow(i); }
-        bool dangling = false;
+        if (live < 4u) { n = 0; break; }                                         // :497-499 (whatever the links look like)
         for (uint32_t i = 0; i < n1; ++i)
         {
             if (S.comp[i] < 0) continue;
@@ -186,8 +188,13 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
             {
                 const int32_t e = S.ring[i * LIT_STRIDE + j];
                 if (!ok(e, n1)) return SURTR_E_TOPOLOGY;
-                if (S.comp[e] < 0) dangling = true;          // renumbered through the stale ID of a clipped vertex: undefined unless the solid goes
-                S.ring[i * LIT_STRIDE + j] = S.id[e];
+                // A link to a clipped vertex that survived the relink is renumbered through that vertex's stale ID (:484-493):
+                // its index after the previous compaction of this call (the link then points at whatever vertex has that index
+                // now -- the reference carries on with it), or -1 if it was never compacted (no vertex: the reference's next
+                // access is out of bounds).  `stale` tells the caller that the result went through this.
+                const int32_t to = S.id[e];
+                if (S.comp[e] < 0) { stale = true; if (to < 0 || (uint32_t)to >= live) return SURTR_E_TOPOLOGY; }
+                S.ring[i * LIT_STRIDE + j] = to;
             }
         }
         uint32_t w = 0;
@@ -204,9 +211,9 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
         }
         n = w;
         if (n < 4u) { n = 0; break; }                                            // :497-499
-        if (dangling) return SURTR_E_TOPOLOGY;
     }
     *n_out = n;
+    if (stale_out != nullptr) *stale_out = stale && n != 0u;
     return 0;
 }
 

@@ -216,7 +216,7 @@ __device__ __attribute__((always_inline)) static inline int clip_image(char* img
 }
 
 // ------------------------------------------------------------- small helpers
-struct ParkOut { int err; uint32_t voff, n, hoff, nh; };
+struct ParkOut { int err; uint32_t voff, n, hoff, nh; bool stale; };
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
 {
     float t = ax * bx + ay * by;
@@ -501,7 +501,7 @@ __device__ __attribute__((noinline)) static ParkOut solid_global(SolidIn in, uin
 {
     Shared& sh = *shp;
     Scratch S = carve(pool, wg);
-    ParkOut o{0, 0u, 0u, 0u, 0u};
+    ParkOut o{0, 0u, 0u, 0u, 0u, false};
     o.err = clip_global(in, F, S, sh, [&](auto& T) -> int {
         if (T.nLive == 0) return 0;
         return park_topo(T, sh, A, o.voff, o.n, o.hoff, o.nh);
@@ -512,25 +512,25 @@ __device__ __attribute__((noinline)) static ParkOut solid_global(SolidIn in, uin
 // Last resort of the one-wave kernels for a solid whose clip raised SURTR_E_TOPOLOGY in the parallel clipper: the literal,
 // single-lane ClipPolyhedron of literal_clip.h on the workgroup's global scratch, result parked like park_topo's.  Out of line,
 // everything by value (see pair_global).  o.err: 0 (o.n == 0: the reference's answer is "empty") or the error that stands.
-struct LitRun { int err; uint32_t n, nh; LitSolid LS; const uint32_t* off; };
+struct LitRun { int err; uint32_t n, nh; LitSolid LS; const uint32_t* off; bool stale; };
 __device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp)
 {
     Shared& sh = *shp;
     Scratch S = carve(pool, wg);
     const uint32_t capV = S.CV < S.CH / LIT_STRIDE ? S.CV : S.CH / LIT_STRIDE;
-    LitRun r{SURTR_E_TOPOLOGY, 0u, 0u, LitSolid{S.pos, S.g_loff, (int32_t*)S.g_ring, S.g_llen, (int32_t*)S.t_ring, S.g_comp, (int32_t*)S.aux0, capV}, S.aux1};
+    LitRun r{SURTR_E_TOPOLOGY, 0u, 0u, LitSolid{S.pos, S.g_loff, (int32_t*)S.g_ring, S.g_llen, (int32_t*)S.t_ring, S.g_comp, (int32_t*)S.aux0, capV}, S.aux1, false};
     __syncthreads();
     if (threadIdx.x == 0)
     {
-        uint32_t n = 0;
-        int rc = literal_clip(in, F, sh.planes, r.LS, &n);
+        uint32_t n = 0; bool stale = false;
+        int rc = literal_clip(in, F, sh.planes, r.LS, &n, &stale);
         if (rc == SURTR_E_CAPACITY) rc = SURTR_E_TOPOLOGY;          // too large for the literal path: the first error stands
         uint32_t h = 0;
         if (rc == 0) for (uint32_t v = 0; v < n; ++v) { S.aux1[v] = h; h += r.LS.len[v]; }
-        sh.misc[2] = (uint32_t)rc; sh.misc[3] = n; sh.misc[4] = h;
+        sh.misc[2] = (uint32_t)rc; sh.misc[3] = n; sh.misc[4] = h; sh.misc[5] = stale ? 1u : 0u;
     }
     __syncthreads();
-    r.err = (int)sh.misc[2]; r.n = sh.misc[3]; r.nh = sh.misc[4];
+    r.err = (int)sh.misc[2]; r.n = sh.misc[3]; r.nh = sh.misc[4]; r.stale = sh.misc[5] != 0u;
     __syncthreads();
     return r;
 }
@@ -549,7 +549,7 @@ __device__ static void literal_write(const LitRun& r, float* pos, uint32_t* loff
 __device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp)
 {
     const LitRun r = literal_run(in, F, pool, wg, shp);
-    ParkOut o{r.err, 0u, 0u, 0u, 0u};
+    ParkOut o{r.err, 0u, 0u, 0u, 0u, r.stale};
     if (r.err != 0 || r.n == 0u) return o;
     uint32_t ioff;
     if (!arena_take(A, *shp, r.n, r.nh, 0, o.voff, o.hoff, ioff)) { o.err = SURTR_E_CAPACITY; return o; }
@@ -558,6 +558,9 @@ __device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, ui
     return o;
 }
 
+#ifndef SURTR_LITERAL_MESH_V
+#define SURTR_LITERAL_MESH_V 2048u      // Mesh solids up to this size may take the literal clip after a topology error (one lane: slow)
+#endif
 #ifndef SURTR_SMALL_WAVES
 #define SURTR_SMALL_WAVES 2
 #endif
@@ -889,8 +892,11 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
 // The Mesh of pair p on global scratch (32-bit topology): solids that do not fit, or outgrew, the LDS topology.  Rare, so
 // out of line and with every argument by value: nothing of the caller's state has to live in memory for it (structures
 // handed over by reference would be written to every lane's private scratch once per pair).  Stores pairs[p] itself.
+// literal != 0: the Mesh goes through the literal single-lane clipper first -- a sliver piece (coincident vertices, doubled
+// neighbours) on which the parallel relink met a walk it cannot follow.  The literal clip of the whole Mesh has the reference's
+// answer wherever the reference has one; it is parked as one solid and takes the island split below as a clip by no planes.
 __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t piece, uint32_t F, ScratchPool pool, uint32_t wg, Arena A,
-                                                            Shared* shp, PairRec* pairs, uint32_t p)
+                                                            Shared* shp, PairRec* pairs, uint32_t p, uint32_t literal)
 {
     Shared& sh = *shp;
     Scratch S = carve(pool, wg);
@@ -902,7 +908,21 @@ __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t p
         if (T.nLive == 0) return 0;
         return park_mesh_islands(T, sh, A, rec);
     };
-    int err = clip_global(min, F, S, sh, consume);
+    int err = 0;
+    bool gone = false;
+    if (literal != 0u)
+    {
+        const ParkOut o = solid_literal(min, F, pool, wg, A, shp);
+        err = o.err;
+        gone = err == 0 && o.n == 0u;
+        if (err == 0 && o.n != 0u)
+        {
+            min = SolidIn{A.pos + 3 * (size_t)o.voff, A.loff + o.voff, A.llen + o.voff, A.nbr, o.n, nullptr, nullptr, nullptr, nullptr, nullptr};
+            F = 0u;
+        }
+        __syncthreads();
+    }
+    if (err == 0 && !gone) err = clip_global(min, F, S, sh, consume);
     __syncthreads();
     if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;
     if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (threadIdx.x == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
@@ -991,9 +1011,15 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
             __syncthreads();
             if (err == SURTR_OVERFLOW)
             {
-                pair_global(P, piece, F, pool, wg, A, &sh, pairs, p);
+                pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 0u);
                 continue;
             }
+        }
+        if (err == SURTR_E_TOPOLOGY && min.nv <= SURTR_LITERAL_MESH_V)
+        {
+            __syncthreads();
+            pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
+            continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
@@ -1344,8 +1370,10 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         if (err == SURTR_E_TOPOLOGY)
         {
             const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh);
-            if (o.err == 0) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
-            else if (o.err != SURTR_E_TOPOLOGY) err = o.err;
+            // (a result that went through a stale ID is no polyhedron, and which one it is depends on the IDs the Convex brought
+            // along from the clips before -- state this engine does not carry: the fragment is flagged below instead)
+            if (o.err == 0 && !o.stale) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
+            else if (o.err != 0 && o.err != SURTR_E_TOPOLOGY) err = o.err;
             __syncthreads();
         }
         if (err == 0 && tid == 0)

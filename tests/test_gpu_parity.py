@@ -486,6 +486,17 @@ def test_degenerate_walk_bound_pair(gpu_engine, oracle):
     assert_event_equal(got, ref)
 
 
+def test_stale_id_sliver_mesh(gpu_engine, oracle):
+    """Refracture fuzz seed 90210, case 1271 (tests/test_literal_clip.py): the single pair, then the whole event."""
+    import test_literal_clip as _lc
+    from helpers import assert_event_equal_flagged
+    from test_refracture import _refracture
+    _lc.check_stale_id_pair(gpu_engine, oracle)
+    c, got, ref, npieces = _refracture(gpu_engine, oracle, 96, 3, 54, 150)
+    assert c.status == 0
+    assert_event_equal_flagged(got, ref)
+
+
 def test_refit_invalid_in_reference_is_isolated(gpu_engine, oracle):
     """Refracture fuzz seed 555002, case 82: one fragment's refit has no valid result in the reference (a one-way link);
     the single fragment first (tests/test_emul_parity.py), then the whole event (200 first-level cells of a 53 x 25 torus,

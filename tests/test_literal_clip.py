@@ -148,3 +148,49 @@ def test_engine_degenerate_pair_emulation(emul_engine, oracle):
 
 def test_engine_degenerate_pair_wide_variant(emul_engine_small, oracle):
     check_degenerate_pair(emul_engine_small, oracle)
+
+
+def load_stale_id_pair():
+    d = np.load(os.path.join(HERE, "golden", "degenerate_mesh_stale_id.npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    return mesh, conv, d["planes"]
+
+
+def check_stale_id_pair(E, oracle):
+    """Refracture fuzz seed 90210, case 1271: a sliver Mesh of six vertices (three coincident pairs, every ring lists a
+    neighbour twice).  Its clip leaves a link to a clipped vertex, which the reference renumbers through that vertex's ID
+    of the plane before (Src/Poly.cpp:484-493) and carries on: four vertices, one ring [1, 2, 2, 2].  The engine's answer
+    is the same solid (the literal clipper follows the stale ID wherever it names a vertex)."""
+    mesh, conv, planes = load_stale_id_pair()
+    eng = E.Engine(0)
+    try:
+        for s in (mesh, conv):
+            assert_solid_equal(eng.clip_polyhedron(s, planes), oracle.clip(s, planes))
+        ref = oracle.clip(mesh, planes)
+        assert ref["pos"].shape[0] == 4 and ref["nbr"][ref["off"][3]:ref["off"][4]].tolist() == [1, 2, 2, 2]
+    finally:
+        eng.close()
+
+
+def test_literal_stale_id_pair(emul_lib_path, oracle):
+    lib = _probe(emul_lib_path)
+    mesh, conv, planes = load_stale_id_pair()
+    for s in (mesh, conv):
+        rc, got = _literal(lib, s, planes)
+        assert rc == 0
+        assert_solid_equal(got, oracle.clip(s, planes))
+
+
+def test_engine_stale_id_pair_emulation(emul_engine, oracle):
+    check_stale_id_pair(emul_engine, oracle)
+
+
+def test_engine_stale_id_whole_event_emulation(emul_engine, oracle):
+    """The whole event the pair comes from (96 first-level cells of a 54 x 150 torus, 3 cells per piece): the Mesh of that pair
+    takes the literal clipper inside k_clip_pairs and the island split behind it."""
+    from helpers import assert_event_equal_flagged
+    from test_refracture import _refracture
+    c, got, ref, npieces = _refracture(emul_engine, oracle, 96, 3, 54, 150)
+    assert c.status == 0
+    assert_event_equal_flagged(got, ref)
