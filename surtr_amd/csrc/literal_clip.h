@@ -48,7 +48,10 @@ __device__ inline int lit_box_side(const float4 pl, const double lo[3], const do
 
 // One lane.  Returns 0 (n_out vertices left in S, compacted: rings of vertex v = S.ring[v * LIT_STRIDE ..], S.len[v] entries),
 // SURTR_E_TOPOLOGY where the reference leaves its domain, SURTR_E_CAPACITY when the solid does not fit.
-__device__ inline int literal_clip(const SolidIn in, const uint32_t F, const float4* planes, LitSolid S, uint32_t* n_out, bool* stale_out = nullptr)
+// ids_set: the vertices come with ID = own index (the solid is the result of an earlier ClipPolyhedron that compacted it, as the
+// Convex that m_refittingTask clips); otherwise with ID = -1 (a solid built from arrays).
+__device__ inline int literal_clip(const SolidIn in, const uint32_t F, const float4* planes, LitSolid S, uint32_t* n_out, bool* stale_out = nullptr,
+                                   bool ids_set = false)
 {
     uint32_t n = in.nv;
     bool stale = false;
@@ -58,7 +61,7 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
         S.pos[3 * v] = in.pos[3 * v]; S.pos[3 * v + 1] = in.pos[3 * v + 1]; S.pos[3 * v + 2] = in.pos[3 * v + 2];
         const uint32_t deg = in.llen[v];
         if (deg > LIT_STRIDE) return SURTR_E_CAPACITY;
-        S.len[v] = deg; S.comp[v] = 1; S.id[v] = -1;
+        S.len[v] = deg; S.comp[v] = 1; S.id[v] = ids_set ? (int32_t)v : -1;
         for (uint32_t j = 0; j < deg; ++j) S.ring[v * LIT_STRIDE + j] = (in.nbr + in.loff[v])[j];
     }
     double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};

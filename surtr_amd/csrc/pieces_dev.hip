@@ -35,7 +35,8 @@ __device__ __forceinline__ uint32_t piece_of(const uint32_t* __restrict__ vo, ui
 // llen + the checks of Poly::ExtractNeighborFromMesh's postcondition (Src/Poly.cpp:253-260): indices in range, no self
 // link, every link has its back link; degree >= 3.  err = max SURTR_E_* seen.
 __global__ void k_piece_check(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ loff,
-                              const int32_t* __restrict__ nbr, uint32_t* __restrict__ llen, uint32_t check, uint32_t* __restrict__ err)
+                              const int32_t* __restrict__ nbr, uint32_t* __restrict__ llen, uint32_t check, uint32_t* __restrict__ err,
+                              uint8_t* __restrict__ dup)
 {
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
@@ -43,9 +44,13 @@ __global__ void k_piece_check(uint32_t V, uint32_t n, const uint32_t* __restrict
     if (hi < lo) { atomicMax(err, (uint32_t)SURTR_E_INVALID); llen[v] = 0; return; }
     const uint32_t deg = hi - lo;
     llen[v] = deg;
+    const uint32_t p = piece_of(vo, n, v), a = vo[p], m = vo[p + 1] - a;
+    // a ring that lists a neighbour twice marks its piece (whether or not the links are validated: fragments turned into
+    // pieces on the device have such rings too)
+    for (uint32_t j = lo + 1u; j < hi; ++j)
+        for (uint32_t q = lo; q < j; ++q) if (nbr[q] == nbr[j]) { dup[p] = 1; j = hi; break; }
     if (!check) return;
     if (deg < 3u) { atomicMax(err, (uint32_t)SURTR_E_TOPOLOGY); return; }
-    const uint32_t p = piece_of(vo, n, v), a = vo[p], m = vo[p + 1] - a;
     const int32_t lv = (int32_t)(v - a);
     for (uint32_t j = lo; j < hi; ++j)
     {
@@ -253,6 +258,7 @@ int reserve_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, uint32_t H,
     R(pos, c_pos, 3 * (size_t)V + 3); R(loff, c_loff, (size_t)V + 1); R(llen, c_llen, V); R(nbr, c_nbr, (size_t)H + 1); R(vo, c_vo, n + 1);
     R(tri, c_tri, V); R(rad, c_rad, V); R(perm, c_perm, V); R(posr_s, c_posr_s, (size_t)V + 1);
     R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, V);
+    R(dup, c_dup, n + 1);
 #undef R
     return SURTR_OK;
 }
@@ -264,7 +270,8 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
     const uint32_t NB = bo_h[n];
     HIPCHK(hipMemcpyAsync(S.bo, bo_h.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
     const dim3 blk(256), gridV((V + 255) / 256);
-    hipLaunchKernelGGL(k_piece_check, gridV, blk, 0, st, V, n, S.vo, S.loff, S.nbr, S.llen, check ? 1u : 0u, ctx->d_upload_err);
+    HIPCHK(hipMemsetAsync(S.dup, 0, (size_t)n + 1, st));
+    hipLaunchKernelGGL(k_piece_check, gridV, blk, 0, st, V, n, S.vo, S.loff, S.nbr, S.llen, check ? 1u : 0u, ctx->d_upload_err, S.dup);
     hipLaunchKernelGGL(k_piece_tri_rad, gridV, blk, 0, st, V, n, S.vo, S.pos, S.loff, S.nbr, S.tri, S.rad);
     hipLaunchKernelGGL(k_piece_box, dim3(n), dim3(SURTR_WG), 0, st, n, S.vo, S.pos, S.box);
     hipLaunchKernelGGL(k_piece_keys, gridV, blk, 0, st, V, n, S.vo, S.pos, S.box, S.key, S.val);

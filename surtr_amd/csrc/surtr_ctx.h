@@ -85,6 +85,10 @@ struct Pieces
     const float* cpos; const uint32_t* cloff; const uint32_t* cllen; const int32_t* cnbr; const uint32_t* cvo; const uint8_t* ctri; const float* crad;
     const uint32_t* cperm; const float4* cposr_s; const float4* cbsph; const uint32_t* cbo;
     uint32_t n;
+    // per piece: 1 = some ring of the solid lists a neighbour twice (a sliver with coincident vertices).  Face walks on such a
+    // solid need not close, and where the reference's bounded walk stops then depends on its vertex count of the moment: these
+    // solids take the literal clipper (literal_clip.h) from the start.
+    const uint8_t* mdup; const uint8_t* cdup;
 };
 
 struct ScratchPool
@@ -154,11 +158,12 @@ struct PieceSet
     uint8_t* tri = nullptr; float* rad = nullptr;
     uint32_t* perm = nullptr; float4* posr_s = nullptr; float4* bsph = nullptr; uint32_t* bo = nullptr;
     float* box = nullptr; unsigned long long* key = nullptr; unsigned long long* key2 = nullptr; uint32_t* val = nullptr;    // Morton sort
+    uint8_t* dup = nullptr; size_t c_dup = 0;       // per piece: a ring lists a neighbour twice
     size_t c_pos = 0, c_loff = 0, c_llen = 0, c_nbr = 0, c_vo = 0, c_tri = 0, c_rad = 0, c_perm = 0, c_posr_s = 0, c_bsph = 0,
            c_bo = 0, c_box = 0, c_key = 0, c_key2 = 0, c_val = 0;
     void release()
     {
-        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val};
+        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val, dup};
         for (void* p : all) if (p) (void)hipFree(p);
         *this = PieceSet();
     }

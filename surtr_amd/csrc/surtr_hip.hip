@@ -512,8 +512,32 @@ __device__ __attribute__((noinline)) static ParkOut solid_global(SolidIn in, uin
 // Last resort of the one-wave kernels for a solid whose clip raised SURTR_E_TOPOLOGY in the parallel clipper: the literal,
 // single-lane ClipPolyhedron of literal_clip.h on the workgroup's global scratch, result parked like park_topo's.  Out of line,
 // everything by value (see pair_global).  o.err: 0 (o.n == 0: the reference's answer is "empty") or the error that stands.
+// True (uniform over the workgroup) when some ring of the solid lists a neighbour twice, or a link has no way back (the result
+// of a clip that went through a stale ID): a solid the literal clipper takes from the start (see Pieces::mdup).
+__device__ static bool solid_is_sliver(const SolidIn in)
+{
+    bool odd = false;
+    for (uint32_t v = threadIdx.x; v < in.nv; v += group_size())
+    {
+        const int32_t* r = in.nbr + in.loff[v];
+        const uint32_t deg = in.llen[v];
+        for (uint32_t j = 0; j < deg; ++j)
+        {
+            const int32_t u = r[j];
+            for (uint32_t q = 0; q < j; ++q) if (r[q] == u) odd = true;
+            if (u < 0 || (uint32_t)u >= in.nv) { odd = true; continue; }
+            const int32_t* ru = in.nbr + in.loff[u];
+            const uint32_t du = in.llen[u];
+            bool back = false;
+            for (uint32_t q = 0; q < du; ++q) if (ru[q] == (int32_t)v) back = true;
+            if (!back) odd = true;
+        }
+    }
+    return __syncthreads_or(odd ? 1 : 0) != 0;
+}
+
 struct LitRun { int err; uint32_t n, nh; LitSolid LS; const uint32_t* off; bool stale; };
-__device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp)
+__device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp, bool ids_set = false)
 {
     Shared& sh = *shp;
     Scratch S = carve(pool, wg);
@@ -523,7 +547,7 @@ __device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint3
     if (threadIdx.x == 0)
     {
         uint32_t n = 0; bool stale = false;
-        int rc = literal_clip(in, F, sh.planes, r.LS, &n, &stale);
+        int rc = literal_clip(in, F, sh.planes, r.LS, &n, &stale, ids_set);
         if (rc == SURTR_E_CAPACITY) rc = SURTR_E_TOPOLOGY;          // too large for the literal path: the first error stands
         uint32_t h = 0;
         if (rc == 0) for (uint32_t v = 0; v < n; ++v) { S.aux1[v] = h; h += r.LS.len[v]; }
@@ -546,9 +570,9 @@ __device__ static void literal_write(const LitRun& r, float* pos, uint32_t* loff
     }
     __syncthreads();
 }
-__device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp)
+__device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp, bool ids_set = false)
 {
-    const LitRun r = literal_run(in, F, pool, wg, shp);
+    const LitRun r = literal_run(in, F, pool, wg, shp, ids_set);
     ParkOut o{r.err, 0u, 0u, 0u, 0u, r.stale};
     if (r.err != 0 || r.n == 0u) return o;
     uint32_t ioff;
@@ -605,10 +629,11 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             SolidIn cin{P.cpos + 3 * (size_t)c0, P.cloff + c0, P.cllen + c0, P.cnbr, P.cvo[piece + 1] - c0, P.ctri + c0, P.crad + c0,
                         P.cperm + c0, P.cposr_s + c0, P.cbsph + P.cbo[piece]};
             uint32_t which = 0;
+            const bool sliver = P.cdup[piece] != 0;      // a ring lists a neighbour twice: the literal clipper below, from the start
 #ifdef SURTR_NO_SMALL_CLIP      // (diagnostic builds: the general clipper alone)
             err = SC_FALLBACK;
 #else
-            err = small_clip(cin, F, sh, U.f, &which);
+            err = sliver ? SURTR_E_TOPOLOGY : small_clip(cin, F, sh, U.f, &which);
 #endif
             if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 80 : 81], 1u);       // (diagnostic: tasks the regular clipper took / handed on)
             if (err == 0)
@@ -989,6 +1014,14 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
             if (T.nLive == 0) return 0;
             return park_mesh_islands(T, sh, A, rec);
         };
+        if (P.mdup[piece] != 0 && min.nv <= SURTR_LITERAL_MESH_V)
+        {
+            // a sliver Mesh (a ring lists a neighbour twice): literal clipper from the start (see pair_global) -- on the regular
+            // kernel's scratch (the half-size kernel's has no room for it: its retry list)
+            if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }
+            else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
+            continue;
+        }
         int err;
         if (HALF)
         {
@@ -1018,7 +1051,8 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         if (err == SURTR_E_TOPOLOGY && min.nv <= SURTR_LITERAL_MESH_V)
         {
             __syncthreads();
-            pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
+            if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }       // (the regular kernel redoes the pair: see above)
+            else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
             continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
@@ -1349,31 +1383,35 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         uint32_t nvoff = 0, ncn = 0, nhoff = 0, nchn = 0;
         // (no small_clip attempt here: the slab planes pass through extreme vertices of the fragment, which are vertices of its
         // Convex as often as not -- measured on configs[3]: 2 385 of 2 692 refits have a vertex exactly in a plane)
-        int err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
-            if (T.nLive == 0) return 0;
-            return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
-        }, &W);
-        __syncthreads();
-#ifdef SURTR_STAMP
-        if (err == SURTR_OVERFLOW) dbg_path |= 1;
-        if (err == SURTR_E_TOPOLOGY) dbg_path |= 2;
-#endif
-        if (err == SURTR_OVERFLOW)
+        int err = SURTR_E_TOPOLOGY;      // a sliver Convex: the literal clipper below, from the start
+        if (!solid_is_sliver(cin))
         {
-            const ParkOut o = solid_global(cin, 8, pool, blockIdx.x, A, &sh);
-            err = o.err; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh;
+            err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
+                if (T.nLive == 0) return 0;
+                return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
+            }, &W);
             __syncthreads();
+#ifdef SURTR_STAMP
+            if (err == SURTR_OVERFLOW) dbg_path |= 1;
+            if (err == SURTR_E_TOPOLOGY) dbg_path |= 2;
+#endif
+            if (err == SURTR_OVERFLOW)
+            {
+                const ParkOut o = solid_global(cin, 8, pool, blockIdx.x, A, &sh);
+                err = o.err; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh;
+                __syncthreads();
+            }
         }
 #ifdef SURTR_STAMP
         if (err == SURTR_E_TOPOLOGY) dbg_path |= 4;
 #endif
         if (err == SURTR_E_TOPOLOGY)
         {
-            const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh);
-            // (a result that went through a stale ID is no polyhedron, and which one it is depends on the IDs the Convex brought
-            // along from the clips before -- state this engine does not carry: the fragment is flagged below instead)
-            if (o.err == 0 && !o.stale) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
-            else if (o.err != 0 && o.err != SURTR_E_TOPOLOGY) err = o.err;
+            // (the Convex is the result of the pair's clip: its vertices carry the IDs of that clip's last compaction, their own
+            // indices -- unless no cell plane cut the piece's Convex at all, which the engine does not track)
+            const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh, true);
+            if (o.err == 0) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
+            else if (o.err != SURTR_E_TOPOLOGY) err = o.err;
             __syncthreads();
         }
         if (err == 0 && tid == 0)
@@ -2308,14 +2346,16 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_single(SolidIn in, const floa
     for (uint32_t k = threadIdx.x; k < F; k += group_size()) sh.planes[k] = planes[k];
     __syncthreads();
     uint32_t n = 0, nh = 0;
-    int err = clip_any(in, F, S, sh, L, [&](auto& T) -> int {
-        if (T.nLive == 0) return 0;
-        const uint2 tot = index_live(T, sh);
-        if (tot.x > cap_v || tot.y > cap_h) return SURTR_E_CAPACITY;
-        write_solid(T, opos, ooff, ollen, onbr, 0, 0);
-        n = tot.x; nh = tot.y;
-        return 0;
-    });
+    int err = SURTR_E_TOPOLOGY;      // a small sliver: the literal clipper below, from the start
+    if (in.nv > SURTR_LITERAL_MESH_V || !solid_is_sliver(in))
+        err = clip_any(in, F, S, sh, L, [&](auto& T) -> int {
+            if (T.nLive == 0) return 0;
+            const uint2 tot = index_live(T, sh);
+            if (tot.x > cap_v || tot.y > cap_h) return SURTR_E_CAPACITY;
+            write_solid(T, opos, ooff, ollen, onbr, 0, 0);
+            n = tot.x; nh = tot.y;
+            return 0;
+        });
     __syncthreads();
     if (err == SURTR_E_TOPOLOGY)
     {
@@ -2749,7 +2789,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     }
     const PieceSet& M = ctx->mset; const PieceSet& C = ctx->cset;
     Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.posr_s, M.bsph, M.bo,
-             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces};
+             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces, M.dup, C.dup};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     const uint32_t* d_pair_order = nullptr;
     if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it

@@ -52,6 +52,7 @@ template <class T> static inline T atomicCAS(T* p, T cmp, T v) { T o = *p; if (o
 
 // one lane per wave: the cross-lane primitives degenerate to the identity
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline int __syncthreads_or(int p) { return p; }
 static inline bool __all(bool p) { return p; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
 
-from helpers import assert_event_equal, fragment, run_event
+from helpers import RTOL, assert_event_equal, fragment, run_event
 from surtr_amd import meshgen, scenes
 
 
@@ -436,39 +436,40 @@ def test_faces_second_tier_and_workgroup_budget(emul_engine, oracle, monkeypatch
 
 def check_refit_invalid_in_reference(E, oracle):
     """Refracture fuzz seed 555002, case 82, fragment 536 (tests/golden/refit_invalid_in_reference.npz: Mesh and Convex of nine
-    vertices each): the reference's refit clips the Convex into something with a one-way link.  The engine keeps the Convex the
-    fragment had, flags the fragment (frag_status, n_failed) and the event stands; asked for that one solid, it says so."""
+    vertices each): the reference's refit leaves a link to a clipped vertex, renumbers it through that vertex's stale ID
+    (Src/Poly.cpp:484-493) and carries on with a Convex of seven vertices that has a one-way link.  The engine's parallel
+    clipper refuses the walk, its literal clipper follows the reference: same seven vertices, same links, event SURTR_OK."""
     from helpers import solid_is_polyhedron
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refit_invalid_in_reference.npz"))
     mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
     conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
     assert solid_is_polyhedron(mesh) and solid_is_polyhedron(conv)
-    assert not solid_is_polyhedron(oracle.refit(conv, mesh, 4))
+    ref = oracle.refit(conv, mesh, 4)
+    assert ref["pos"].shape[0] == 7 and not solid_is_polyhedron(ref)
     cube = scenes.cube_scene(8)
     eng = E.Engine(0)
     try:
-        with pytest.raises(E.SurtrError) as ei:
-            eng.refit_solid(mesh, conv)
-        assert ei.value.code == E.E_TOPOLOGY
-        # among other fragments: the event stands, this one keeps its Convex and is flagged
+        got = eng.refit_solid(mesh, conv)
+        assert np.array_equal(got["off"], ref["off"]) and np.array_equal(got["nbr"], ref["nbr"])
+        assert np.allclose(got["pos"], ref["pos"], rtol=RTOL, atol=1e-6)
+        # among other fragments
         eng.load_fragments([cube["mesh"], mesh, cube["mesh"]], [cube["convex"], conv, cube["convex"]])
         eng.event_refit()
         c = eng.event_counts()
-        got = eng.download()
-        assert c.status == 0 and c.n_failed == 1
-        assert got["frag_status"].tolist() == [0, E.E_TOPOLOGY, 0]
-        kept = fragment(got, 1, "conv")
-        assert np.array_equal(kept["off"], conv["off"]) and np.array_equal(kept["nbr"], conv["nbr"]) and np.array_equal(kept["pos"], conv["pos"])
+        ev = eng.download()
+        assert c.status == 0 and c.n_failed == 0 and not ev["frag_status"].any()
+        r1 = fragment(ev, 1, "conv")
+        assert np.array_equal(r1["off"], ref["off"]) and np.array_equal(r1["nbr"], ref["nbr"])
         ref0 = oracle.refit(cube["convex"], cube["mesh"], 4)
         for k in (0, 2):
-            r = fragment(got, k, "conv")
+            r = fragment(ev, k, "conv")
             assert np.array_equal(r["off"], ref0["off"]) and np.array_equal(r["nbr"], ref0["nbr"])
-        # a triangulation afterwards leaves the flag where it is
+        # the invalid Convex goes on through the triangulation of the event (its Mesh is what is triangulated)
         eng.event_triangulate()
-        assert eng.event_counts().n_failed == 1 and eng.download()["frag_status"].tolist() == [0, E.E_TOPOLOGY, 0]
+        assert eng.event_counts().status == 0
     finally:
         eng.close()
 
 
-def test_refit_invalid_in_reference_is_isolated(emul_engine, oracle):
+def test_refit_result_that_is_no_polyhedron(emul_engine, oracle):
     check_refit_invalid_in_reference(emul_engine, oracle)

@@ -194,3 +194,32 @@ def test_engine_stale_id_whole_event_emulation(emul_engine, oracle):
     c, got, ref, npieces = _refracture(emul_engine, oracle, 96, 3, 54, 150)
     assert c.status == 0
     assert_event_equal_flagged(got, ref)
+
+
+def check_sliver_convex_walk_bound(E, oracle):
+    """Refracture fuzz seed 13579, case 84 (tests/golden/sliver_convex_walk_bound.npz): a seven-vertex Convex with doubled
+    neighbours.  After the first plane one of the second plane's relink walks wanders among clipped vertices; the reference
+    stops it after as many steps as the solid has vertices at that moment and ends with nothing, the parallel clipper -- whose
+    slots still hold the vertices clipped before -- let it run on to a new vertex and returned a tetrahedron (one fragment too
+    many in the event).  Solids with a doubled neighbour now take the literal clipper from the start."""
+    d = np.load(os.path.join(HERE, "golden", "sliver_convex_walk_bound.npz"))
+    mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
+    conv = {"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}
+    planes = d["planes"]
+    eng = E.Engine(0)
+    try:
+        for k in range(1, planes.shape[0] + 1):
+            for s in (conv, mesh):
+                assert_solid_equal(eng.clip_polyhedron(s, planes[:k]), oracle.clip(s, planes[:k]))
+        assert oracle.clip(conv, planes[:2])["pos"].shape[0] == 0
+        # as a piece of an event: the cell that the planes belong to yields no fragment
+        c = eng.upload_pieces([mesh], [conv])
+        eng.upload_planes(np.asarray([0, planes.shape[0]], np.uint32), planes)
+        c = eng.fracture_event(0, 1, flags=3)
+        assert c.status == 0 and c.n_frag == 0
+    finally:
+        eng.close()
+
+
+def test_sliver_convex_walk_bound_emulation(emul_engine, oracle):
+    check_sliver_convex_walk_bound(emul_engine, oracle)
