@@ -584,6 +584,7 @@ __device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, ui
 
 #ifndef SURTR_LITERAL_MESH_V
 #define SURTR_LITERAL_MESH_V 2048u      // Mesh solids up to this size may take the literal clip after a topology error (one lane: slow)
+#define SURTR_LITERAL_START_V 64u       // Mesh solids up to this size take it from the start when a ring lists a neighbour twice
 #endif
 #ifndef SURTR_SMALL_WAVES
 #define SURTR_SMALL_WAVES 2
@@ -784,7 +785,9 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             // not pre-passed here: the whole Mesh decides between the half-size kernel and the regular one
             if (tid == 0)
             {
-                if (half_on && V <= pool.VMAX && fits_half(V, P.mloff[m0 + V] - P.mloff[m0], capVs)) enqueue_half(p, 1u);
+                // (a sliver Mesh goes to the regular kernel, which has the scratch for the literal clipper: see clip_pairs_body)
+                const bool sliver = P.mdup[piece] != 0 && V <= SURTR_LITERAL_START_V;
+                if (half_on && !sliver && V <= pool.VMAX && fits_half(V, P.mloff[m0 + V] - P.mloff[m0], capVs)) enqueue_half(p, 1u);
                 else enqueue(p, V > pool.VMAX ? 13u : 0u);
             }
             continue;
@@ -1014,10 +1017,11 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
             if (T.nLive == 0) return 0;
             return park_mesh_islands(T, sh, A, rec);
         };
-        if (P.mdup[piece] != 0 && min.nv <= SURTR_LITERAL_MESH_V)
+        if (P.mdup[piece] != 0 && min.nv <= SURTR_LITERAL_START_V)
         {
-            // a sliver Mesh (a ring lists a neighbour twice): literal clipper from the start (see pair_global) -- on the regular
-            // kernel's scratch (the half-size kernel's has no room for it: its retry list)
+            // a sliver Mesh (a few vertices, a ring lists a neighbour twice): literal clipper from the start (see pair_global) --
+            // on the regular kernel's scratch (the half-size kernel's has no room for it: its retry list).  A larger Mesh with
+            // such a ring keeps the parallel clipper (one lane would take milliseconds for it) and falls back only on an error.
             if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }
             else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
             continue;
