@@ -137,6 +137,14 @@ def kdop_planes(points, normals, ach=False, max_axis_scale=0.0, gap_inv=1.0):
     return p.reshape(-1, 4)
 
 
+def links_off_the_array(reset=True):
+    """How often, since the last reset, ClipPolyhedron's compaction left a link that names no vertex (Src/Poly.cpp:484-493
+    through an ID of -1 or beyond the new size): past that point the reference reads outside its vertex array."""
+    f = lib().orc_links_off_the_array
+    f.restype = ctypes.c_long
+    return int(f(ctypes.c_int(int(reset))))
+
+
 def refit(convex, mesh, point_limit=4):
     cp, co, cn = _solid_args(convex)
     mp, mo, mn = _solid_args(mesh)

@@ -337,7 +337,7 @@ __device__ __forceinline__ int32_t face_next_in(const int32_t* ring, uint32_t le
 // (from the dry run -- walks only cross clipped vertices, whose rings the relink never changes).
 // (T by value: a reference would force the caller's Topo into every lane's private memory for the whole plane loop.)
 template <class TT>
-__device__ void relink_serial(const Topo<TT> T, uint32_t n0, uint32_t n1, const uint32_t* snapoff, const uint32_t* cap,
+__device__ void relink_serial(const Topo<TT> T, uint32_t n0, uint32_t n1, uint32_t nref, const uint32_t* snapoff, const uint32_t* cap,
                               const uint32_t* zlist, uint32_t nz, const uint32_t* slist, uint32_t ns,
                               const uint32_t* wcur, const uint32_t* wprev, const uint32_t* arrive, const uint32_t* srcof, Shared& sh)
 {
@@ -359,7 +359,7 @@ __device__ void relink_serial(const Topo<TT> T, uint32_t n0, uint32_t n1, const 
             else
             {
                 uint32_t steps = 0;
-                while (cur < TT::SENT && T.cmp(cur) == -1 && steps++ < n1)
+                while (cur < TT::SENT && T.cmp(cur) == -1 && steps++ < nref)      // (the reference's bound: its vertex count)
                 {
                     const uint32_t hold = cur;
                     cur = face_next(T.ring + T.loff[cur], T.llen[cur], prev);
@@ -976,6 +976,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
     if (T.nLive == 0) return 0;
     bool squeezed = false;
     uint32_t it = 0;
+    const uint32_t dropTotal = in.nv > T.nS ? in.nv - T.nS : 0u;      // vertices of the input that the band reduction left out
     for (uint32_t q = tid; q < 24; q += group_size()) (&sh.pf[0][0])[q] = 0;
     __syncthreads();
     for (uint32_t k = 0; k < F; ++k)
@@ -1153,6 +1154,11 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
         }
         squeezed = false;
         const uint32_t n0 = nS, n1 = nS + M;
+        // The reference bounds every relink walk by the number of vertices its (compacted) solid has at this point (:389-394):
+        // live vertices, the dropped ones among them, plus this plane's new ones -- fewer than the n1 slots here, which still
+        // hold the vertices clipped by earlier planes.  On a regular solid no walk comes near either bound; on a sliver whose
+        // walk wanders among clipped vertices the place where it stops is the reference's result.
+        const uint32_t nref = T.nLive + (k ? sh.hist[k - 1u] : dropTotal) + M;
         if ((clist.l || cutcnt.l) && T.hUsed + 3u * M + 8u > wtop)
         {
             // the new rings would run into the lists: move them out (a band that nearly fills the ring area)
@@ -1382,7 +1388,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
                     {
                         const uint32_t cc = c < TT::SENT ? c : 0u;
                         const int cm = T.cmp(cc); const uint32_t lo = T.loff[cc], len = T.llen[cc];
-                        if (!(c < TT::SENT && cm == -1 && steps++ < n1)) break;
+                        if (!(c < TT::SENT && cm == -1 && steps++ < nref)) break;
                         const I* r = T.ring + lo;
                         if (len == 3u && (uint32_t)r[1] == prev && (uint32_t)r[0] != prev)
                         {
@@ -1444,7 +1450,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
                     const uint32_t jn = r[j];
                     if (jn >= TT::SENT || T.cmp(jn) != -1) continue;
                     uint32_t prev = v, c = jn, steps = 0;
-                    while (c < TT::SENT && T.cmp(c) == -1 && steps++ < n1)
+                    while (c < TT::SENT && T.cmp(c) == -1 && steps++ < nref)
                     {
                         const uint32_t hold = c;
                         c = face_next(T.ring + T.loff[c], T.llen[c], prev);
@@ -1518,7 +1524,7 @@ __device__ __attribute__((always_inline)) inline int clip_planes(Topo<TT>& T, co
                 }
             }
             __syncthreads();
-            if (tid == 0) relink_serial(T, n0, n1, snapoff, cap, zlist, zc, slist, ns, wcur, wprev, arrive, srcof, sh);
+            if (tid == 0) relink_serial(T, n0, n1, nref, snapoff, cap, zlist, zc, slist, ns, wcur, wprev, arrive, srcof, sh);
             __syncthreads();
             if (sh.flagErr) return 2;
             // easy vertices: [source, target, kept]

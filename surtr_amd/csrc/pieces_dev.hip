@@ -310,7 +310,7 @@ void set_piece_stats(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const uint
     ctx->tot_mv = mvo[n]; ctx->tot_mh = mho[n]; ctx->pair_order_count = 0;
     ctx->half_on = 4ull * small >= 3ull * n;
     if (const char* e = getenv("SURTR_HALF")) ctx->half_on = atoi(e) != 0;      // tests: force either way
-    ctx->have_event = false;
+    ctx->have_event = false; ctx->frags_of_pieces = false;
 }
 
 int finish_upload(surtr_ctx* ctx, uint32_t n, bool check)
@@ -404,7 +404,7 @@ int surtr_transform_pieces(surtr_ctx* ctx, uint32_t n, const float* world)
         rc = derive_set(ctx, S, n, V, sphere_offsets(n, vo.data()), false);
         if (rc) return rc;
     }
-    ctx->have_event = false;
+    ctx->have_event = false; ctx->frags_of_pieces = false;
     HIPCHK(hipStreamSynchronize(st));
     return SURTR_OK;
 }
@@ -467,6 +467,7 @@ int surtr_pieces_from_event(surtr_ctx* ctx, const uint8_t* keep, uint32_t* n_out
     }
     set_piece_stats(ctx, n, vo[0].data(), ho[0].data(), vo[1].data(), ho[1].data());
     ctx->have_event = true;       // the event's fragments are still in the arena: they can be downloaded after this call
+    ctx->frags_of_pieces = false; // (but the pieces they came from are gone)
     return finish_upload(ctx, n, false);
 }
 

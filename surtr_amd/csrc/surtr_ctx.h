@@ -199,6 +199,7 @@ struct surtr_ctx
 {
     int device = 0;
     uint32_t n_wg_faces_alloc = 0;
+    bool frags_of_pieces = false;      // the current fragments are an event's over the resident pieces (k_refit may look at the piece a Convex came from)
     // what the CUs can hold (surtr_create); max_wg* below are those, cut down to what the scratch of the current pieces leaves room for
     uint32_t hw_wg = 512, hw_wg_faces = 1024, hw_wg_prep = 1792, hw_wg_big = 48, budget_vmax = 0xFFFFFFFFu, budget_hmax = 0xFFFFFFFFu;
     uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;

@@ -1244,7 +1244,8 @@ __device__ __forceinline__ float hull_vol(const float* a, const float* b, const 
 
 __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ frags, const surtr_counts* __restrict__ counts,
                                                     ScratchPool pool, Arena A, const uint32_t* __restrict__ forder, uint32_t cap_frags,
-                                                    uint32_t* __restrict__ frag_status)
+                                                    uint32_t* __restrict__ frag_status, const float* __restrict__ piece_cpos,
+                                                    const uint32_t* __restrict__ piece_cvo)
 {
     __shared__ Shared sh;
     __shared__ ArgF slotF[SURTR_NWAVE];
@@ -1411,9 +1412,19 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
 #endif
         if (err == SURTR_E_TOPOLOGY)
         {
-            // (the Convex is the result of the pair's clip: its vertices carry the IDs of that clip's last compaction, their own
-            // indices -- unless no cell plane cut the piece's Convex at all, which the engine does not track)
-            const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh, true);
+            // The Convex is the result of the pair's clip: its vertices carry the IDs of that clip's last compaction, their own
+            // indices -- unless no cell plane cut the piece's Convex, which then is a copy of the piece's with the IDs it came
+            // with (-1: built from arrays).  A cut changes the vertex set, so "uncut" = same vertices as the piece's Convex.
+            bool ids_set = piece_cpos != nullptr;
+            if (piece_cpos != nullptr)
+            {
+                const uint32_t c0 = piece_cvo[fr.piece], pn = piece_cvo[fr.piece + 1] - c0;
+                bool differs = pn != fr.cv_n;
+                if (!differs)
+                    for (uint32_t i = tid; i < 3u * pn; i += group_size()) if (piece_cpos[3 * (size_t)c0 + i] != cin.pos[i]) differs = true;
+                ids_set = __syncthreads_or(differs ? 1 : 0) != 0;
+            }
+            const ParkOut o = solid_literal(cin, 8, pool, blockIdx.x, A, &sh, ids_set);
             if (o.err == 0) { err = 0; nvoff = o.voff; ncn = o.n; nhoff = o.hoff; nchn = o.nh; }
             else if (o.err != SURTR_E_TOPOLOGY) err = o.err;
             __syncthreads();
@@ -2888,7 +2899,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         uint32_t g_refit = ctx->n_wg_small;
         if (both) g_refit = std::min(g_refit, ctx->max_wg_faces / 4u * 5u);
         if (both) if (const char* e = getenv("SURTR_REFIT_WG_BOTH")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_small) g_refit = v; }
-        hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status);
+        hipLaunchKernelGGL(k_refit, dim3(g_refit), dim3(SURTR_LANES), 0, st_refit, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status,
+                           (const float*)ctx->cset.pos, (const uint32_t*)ctx->cset.vo);
         PROF_END_ON(2, st_refit);
     }
     if (flags & SURTR_EVT_RENDER)
@@ -2918,7 +2930,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     PROF_END(4);
     HIPCHK(hipGetLastError());
-    ctx->have_event = true; ctx->last_flags = flags; ctx->last_current = false;
+    ctx->have_event = true; ctx->last_flags = flags; ctx->last_current = false; ctx->frags_of_pieces = true;
     return SURTR_OK;
 }
 
@@ -3018,7 +3030,8 @@ int surtr_event_refit(surtr_ctx* ctx)
     // k_refit pulls fragments from work queue 6
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 6, 0, 4, st));
     PROF_BEGIN(2);
-    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status);
+    hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status,
+                       ctx->frags_of_pieces ? (const float*)ctx->cset.pos : (const float*)nullptr, ctx->frags_of_pieces ? (const uint32_t*)ctx->cset.vo : (const uint32_t*)nullptr);
     PROF_END(2);
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
@@ -3129,7 +3142,7 @@ int surtr_load_fragments(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const 
     hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));       // the staging vectors go out of scope
-    ctx->have_event = true; ctx->last_flags = 0; ctx->last_current = false;
+    ctx->have_event = true; ctx->last_flags = 0; ctx->last_current = false; ctx->frags_of_pieces = false;
     return SURTR_OK;
 }
 

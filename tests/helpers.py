@@ -79,7 +79,13 @@ def assert_event_equal_flagged(got, ref, render=True):
         if st[k] == 0:
             assert same, ("conv", k)
         elif not same:
-            assert not solid_is_polyhedron(rc), ("fragment flagged although the reference's refitted Convex is a polyhedron", k)
+            # the engine kept the un-refitted Convex: either the reference's result is no polyhedron, or on its way there it
+            # stored a link that names no vertex (whatever it returns after that is an accident of its heap)
+            from oracle import oracle as _O
+            _O.links_off_the_array(reset=True)
+            _O.refit(gc, gm, 4)
+            undefined = _O.links_off_the_array(reset=True) > 0
+            assert undefined or not solid_is_polyhedron(rc), ("fragment flagged although the reference's refit is well defined", k)
             assert solid_is_polyhedron(gc), ("conv kept", k)
         if render:
             a, b = int(got["idx_off"][k]), int(got["idx_off"][k + 1]); c, d = int(ref["idx_off"][k]), int(ref["idx_off"][k + 1])
