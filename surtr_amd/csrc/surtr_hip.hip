@@ -26,6 +26,7 @@
 #include "surtr_ctx.h"
 #include "small_clip.h"
 #include "literal_clip.h"
+#include "wave_clip.h"
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
 template <uint32_t LV, uint32_t LH>
@@ -1111,6 +1112,95 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
     __shared__ Shared sh;
     __shared__ LdsTopoBig L;
     clip_pairs_body(sh, L, pool, wg_base + blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, A, IA, pairs, pair_list, order, nullptr, 15, 14, 11u);
+}
+
+// -------------------------------------------------------------- k_clip_pairs_wave
+// The same pairs through the record clipper (wave_clip.h): regular planes only, one LDS access per step of a plane's dependent
+// chain.  It takes the tickets of cost classes cls_hi..cls_lo like k_clip_pairs; a pair it cannot take (no narrow image, a
+// sliver piece, a cell of more than 64 planes) or has to give up (a plane with an in-plane vertex, an irregular cap, a ring of
+// more than seven entries, out of room: WC_BAIL) goes -- untouched, nothing of it published -- to the retry list (class 0
+// of the half table), which a launch of k_clip_pairs behind this kernel takes.
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_wave(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
+{
+    __shared__ WcLds W;
+    const uint32_t tid = threadIdx.x;
+    // this workgroup's scratch slot, used raw: sorted records + positions of a band's originals, positions of the cut points
+    char* slot = pool.base + (size_t)blockIdx.x * pool.per_wg;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint32_t t = atomicAdd(&A.cursors[qcur], 1u), p = 0xFFFFFFFFu;
+            for (int cls = cls_hi; cls >= cls_lo; --cls)
+            {
+                const uint32_t cnt = A.cursors[16 + cls];
+                if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
+                t -= cnt;
+            }
+            W.misc[7] = p;
+        }
+        __syncthreads();
+        const uint32_t p = W.misc[7];
+        if (p >= n_pairs) break;
+        PairRec rec = pairs[p];
+        if (rec.cv_n == 0 || rec.status != 0) continue;       // empty Convex: the Mesh is not clipped (:1467-1468)
+        if (rec.img_fmt == IMG_EMPTY) continue;
+        const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
+        const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
+        const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
+        int err = WC_BAIL;
+        if (rec.img_fmt == IMG_NARROW && P.mdup[piece] == 0 && F <= WC_MAXF)
+        {
+            for (uint32_t k = tid; k < F; k += group_size()) W.planes[k] = planes[f0 + k];
+            const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
+            const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
+            const char* img = IA.base + (size_t)rec.img_off * 16u;
+            const ImgLayout lay = img_layout(F, nbV, rec.img_n, rec.img_h);
+            const WcImg im{(const uint16_t*)(img + lay.loff), (const uint8_t*)(img + lay.llen), (const uint8_t*)(img + lay.comp),
+                           (const uint16_t*)(img + lay.ring), (const float*)(img + lay.pos), (const uint32_t*)(img + lay.hist),
+                           (const uint32_t*)(img + lay.zhist), (const uint32_t*)(img + lay.nzero), rec.img_n, rec.img_h};
+            unsigned long long zmask = 0ull;
+            WcOut o{0u, 0u, 0u, 0u};
+            WcCtr ctr{0u, 0u};
+#ifdef SURTR_STAMP
+            if (tid == 0) for (int q = 0; q < 32; ++q) W.ph[q] = 0ull;
+#endif
+            bool fits = false;
+            const WcGlob g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WcLds::kNR, fits);
+            if (fits) err = wc_load(W, im, F, g, zmask, ctr, A.cursors + 96);
+            if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WcLds::kNR, o, ctr, A.cursors + 96);
+            if (err == 0 && o.nLive != 0u) err = wc_park(W, F, rec.img_n, o, g, A, rec, ctr, A.cursors + 96);
+#ifdef SURTR_STAMP
+            __syncthreads();
+            if (tid == 0)
+            {
+                for (int q = 0; q < 29; ++q) if (q != 22 && q != 23 && W.ph[q]) atomicAdd(&g_wstamp[q], W.ph[q]);
+                // LDS the pair needed at its worst plane, and at its worst plane from the third on (classes of 4 KiB)
+                if (err == 0)
+                {
+                    unsigned long long c = W.ph[31] / 4096ull, c2 = W.ph[29] / 4096ull;
+                    atomicAdd(&g_wstamp[32 + (int)(c > 15ull ? 15ull : c)], 1ull);
+                    atomicAdd(&g_wstamp[48 + (int)(c2 > 15ull ? 15ull : c2)], 1ull);
+                }
+            }
+#endif
+        }
+        if (tid == 0) atomicAdd(&A.cursors[err == WC_BAIL ? 89 : 88], 1u);       // (diagnostic: pairs the record clipper took / handed on)
+        if (err == WC_BAIL)
+        {
+            if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p;
+            continue;
+        }
+        if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
+        if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+        if (tid == 0) pairs[p] = rec;
+    }
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -2857,8 +2947,16 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
                            ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
     PROF_END(8);
+    // the regular pairs on one wave each (wave_clip.h); what it hands on comes back through the retry launch below
+    bool wave_on = true;
+    if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
+    PROF_BEGIN_ON(11, st2);
+    if (n_pairs && wave_on)
+        hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
+    PROF_END_ON(11, st2);
     PROF_BEGIN_ON(0, st2);
-    if (n_pairs)
+    if (n_pairs && !wave_on)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
     PROF_END_ON(0, st2);
@@ -2872,8 +2970,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
     // (it reuses the scratch slots of the first launch)
     PROF_BEGIN_ON(10, st2);
-    if (n_pairs && ctx->half_on)
-        hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+    if (n_pairs && (ctx->half_on || wave_on))
+        hipLaunchKernelGGL(k_clip_pairs, dim3(wave_on ? n_wg : std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
     PROF_END_ON(10, st2);
     HIPCHK(hipEventRecord(ctx->ev_big, st2));
@@ -3286,6 +3384,18 @@ int surtr_debug_stamps2(unsigned long long out[64], int reset)
     if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(z)); }
     return SURTR_OK;
 }
+int surtr_debug_stamps_wave(unsigned long long out[64], int reset)
+{
+#ifdef SURTR_STAMP
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wstamp), sizeof(unsigned long long) * 64) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp), z, sizeof(z)); }
+    return SURTR_OK;
+#else
+    (void)out; (void)reset;
+    return SURTR_E_STATE;
+#endif
+}
+
 int surtr_debug_stamps(unsigned long long out[96], int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 96) != hipSuccess) return SURTR_E_HIP;

@@ -1,0 +1,735 @@
+// wave_clip.h -- the regular planes of Poly::ClipPolyhedron (Src/Poly.cpp:265-500) for the band of a Mesh, on a layout where
+// every step of a plane's dependent chain is ONE memory access ("record clipper").
+//
+// clip_core.h's plane loop keeps the topology of the whole band in LDS as offset / length / state arrays over slots: a walk
+// step is four dependent LDS round trips, the clipped set of a plane comes from a scan over every slot, dead slots are squeezed
+// out when they run out, and the band (thousands of vertices of which a plane touches a few hundred) decides how many pairs a
+// CU holds.  Here:
+//
+//   records   a vertex is one aligned 16-byte record: seven 16-bit ring entries + a 16-bit tail (first clipping plane and ring
+//             length while alive; position in the plane's clipped list while it is being clipped).  A walk step, a
+//             kept-neighbour count or a back-link patch reads ONE record.  Cut points have the ring
+//             [predecessor, successor, kept end] a regular relink leaves.
+//   buckets   the originals of the band are sorted by the first plane that clips them (stable: ascending original index
+//             inside a bucket) and stay in HBM / L2.  The originals a plane clips are a contiguous range of records, copied
+//             into LDS when their plane comes ("stage"): no selection scan, and only what a plane works on is in LDS.  Whether
+//             an original neighbour is kept is a comparison of its id with the bucket boundary: no lookup.  The back-link of a
+//             kept original is patched where it lives (one 16-byte read, one 2-byte write, beside the position gathers).
+//   nlist     the cut points that are still alive (records in LDS), in creation order: one ordered filter per plane gives
+//             the clipped cut points in the reference's order (Src/Poly.cpp:333-357 numbers new vertices by (clipped vertex,
+//             slot); the compaction :464-495 keeps creation order) and, at the end, the output order.
+//   no slots  ids are record addresses and order is carried by bucket / nlist positions, so nothing is ever renumbered,
+//             squeezed or tombstoned; the records of clipped cut points go to a free list.
+//
+// Only REGULAR planes are handled (what clip_core.h calls the fast relink): no live vertex in the plane, no ring that lists a
+// kept neighbour twice, every new vertex the successor of exactly one other, rings of at most seven entries, cells of at most
+// 64 planes.  Anything else -- and any capacity limit -- returns WC_BAIL before the pair has published anything, and the
+// caller hands the pair to the general clipper, which reproduces the reference's in-plane / degenerate behaviour.  Results
+// are bit-identical to clip_planes(): the same order rules, the same float program (plane_dist / side_of /
+// PlaneLineIntersection :746-751).  Written for a workgroup of any number of waves (blockDim.x): loops stride by the group,
+// ordered scans give every wave a contiguous range.
+#pragma once
+#include "clip_core.h"
+
+#ifndef SURTR_WR
+#define SURTR_WR 3584u          // 16-byte units of LDS per pair: cut-point records (8 bytes each) from the bottom, stage + lists from the top (56 KiB)
+#endif
+#ifndef SURTR_WNL
+#define SURTR_WNL 2560u         // cut points alive at any time
+#endif
+#ifndef SURTR_WWALK0
+#define SURTR_WWALK0 4u         // walk steps before the runs of clipped vertices are collapsed by pointer jumping
+#endif
+#define WC_MAXF 64u             // planes per cell the record clipper takes (in-plane mask = one 64-bit word)
+#define WC_MAXN 0x2000u         // band vertices (ids of originals are below, ids of cut points from here on)
+#define WC_BAIL 102             // internal: not regular / does not fit -> the general clipper takes the pair
+#define WC_SENT 0xFFFEu         // ring entry: a vertex the band reduction dropped (InLds::SENT)
+#define WC_NONE 0xFFFFu
+// why[site]: pairs handed on per rule (Arena::cursors[96 + site], surtr_queue_stats); the single-lane CPU build of the tests
+// also says so on stderr
+#define WC_RET(site) do { if (threadIdx.x == 0u) atomicAdd(&why[site], 1u); SURTR_DBG("record clip: pair handed on at site %d\n", site); return WC_BAIL; } while (0)
+// Diagnostic build only (-DSURTR_STAMP): lane-0 cycles per phase
+#ifdef SURTR_STAMP
+__device__ unsigned long long g_wstamp[64];
+#define WSTAMP_DECL unsigned long long ws_t0 = __builtin_readcyclecounter(), ws_t1
+// (accumulated in LDS, flushed once per pair by the kernel: a global atomic per phase would be what the stamps measure)
+#define WSTAMP(i) do { if (threadIdx.x == 0u) { ws_t1 = __builtin_readcyclecounter(); W.ph[i] += ws_t1 - ws_t0; ws_t0 = ws_t1; } } while (0)
+#define WCOUNT(i, v) do { if (threadIdx.x == 0u) W.ph[i] += (unsigned long long)(v); } while (0)
+#else
+#define WSTAMP_DECL
+#define WSTAMP(i) do { } while (0)
+#define WCOUNT(i, v) do { } while (0)
+#endif
+
+namespace surtr {
+
+struct alignas(16) WcW4 { uint32_t a, b, c, d; };
+
+// All LDS record / list accesses go through memcpy on a byte array (no type punning for the optimiser to trip over); the
+// alignment hints make them single ds_read / ds_write instructions.  i16: index in 16-bit words from the start of the array.
+__device__ __forceinline__ uint32_t wc_ld16(const unsigned char* B, uint32_t i16) { uint16_t v; __builtin_memcpy(&v, __builtin_assume_aligned(B + 2u * (size_t)i16, 2), 2); return v; }
+__device__ __forceinline__ void wc_st16(unsigned char* B, uint32_t i16, uint32_t v) { const uint16_t x = (uint16_t)v; __builtin_memcpy(__builtin_assume_aligned(B + 2u * (size_t)i16, 2), &x, 2); }
+__device__ __forceinline__ uint32_t wc_ld32(const unsigned char* B, uint32_t i16) { uint32_t v; __builtin_memcpy(&v, __builtin_assume_aligned(B + 2u * (size_t)i16, 4), 4); return v; }
+__device__ __forceinline__ void wc_st32(unsigned char* B, uint32_t i16, uint32_t v) { __builtin_memcpy(__builtin_assume_aligned(B + 2u * (size_t)i16, 4), &v, 4); }
+__device__ __forceinline__ uint32_t wc_ld8(const unsigned char* B, uint32_t i8) { return B[i8]; }
+__device__ __forceinline__ void wc_st8(unsigned char* B, uint32_t i8, uint32_t v) { B[i8] = (unsigned char)v; }
+
+// A record in registers: entries 0..6 in w0..w3 (two per word), tail = high half of w3.
+//   alive:         tail = first clipping plane (SURTR_NEVER: none) | ring length << 8
+//   being clipped: tail = 0x8000 | ring length << 12 | position in the plane's clipped list
+// Unused entries hold WC_NONE.
+struct WcRec
+{
+    uint32_t w0, w1, w2, w3;
+    __device__ __forceinline__ uint32_t tail() const { return w3 >> 16; }
+    __device__ __forceinline__ uint32_t e(uint32_t q) const
+    {
+        const uint32_t w = q < 2u ? w0 : (q < 4u ? w1 : (q < 6u ? w2 : w3));
+        return (q & 1u) ? (w >> 16) : (w & 0xFFFFu);
+    }
+    // first slot below len that holds `who` (std::find, Src/Poly.cpp:34-41); len when absent
+    __device__ __forceinline__ uint32_t find(uint32_t who, uint32_t len) const
+    {
+        const uint32_t x = who | (who << 16);
+        const uint32_t d0 = w0 ^ x, d1 = w1 ^ x, d2 = w2 ^ x, d3 = w3 ^ x;
+        uint32_t m = 0;
+        m |= (d0 & 0xFFFFu) ? 0u : 1u;  m |= (d0 >> 16) ? 0u : 2u;
+        m |= (d1 & 0xFFFFu) ? 0u : 4u;  m |= (d1 >> 16) ? 0u : 8u;
+        m |= (d2 & 0xFFFFu) ? 0u : 16u; m |= (d2 >> 16) ? 0u : 32u;
+        m |= (d3 & 0xFFFFu) ? 0u : 64u;
+        m &= (1u << len) - 1u;
+        return m ? (uint32_t)__builtin_ctz(m) : len;
+    }
+};
+// The record of a vertex that is in LDS, by its byte offset: an original (16 bytes, in the plane's stage) or a cut point (8 bytes
+// in the pool: [pred, succ, kept end, tail]; presented with entries 3..6 = WC_NONE and the tail in its usual place).
+struct alignas(8) WcW2 { uint32_t a, b; };
+__device__ __forceinline__ WcRec wc_rec(const unsigned char* B, uint32_t byte_off, bool cut)
+{
+    WcW2 lo, hi;
+    __builtin_memcpy(&lo, __builtin_assume_aligned(B + byte_off, 8), 8);
+    __builtin_memcpy(&hi, __builtin_assume_aligned(B + byte_off + 8u, 8), 8);      // (a cut point: the next record's bytes, unused)
+    WcRec r;
+    r.w0 = lo.a;
+    r.w1 = cut ? (lo.b | 0xFFFF0000u) : lo.b;
+    r.w2 = cut ? 0xFFFFFFFFu : hi.a;
+    r.w3 = cut ? ((lo.b & 0xFFFF0000u) | 0xFFFFu) : hi.b;
+    return r;
+}
+// a 16-byte record at unit `unit` (park: none; loader / global copies use WcW4 directly)
+
+template <uint32_t NR>
+struct alignas(16) WcLdsT
+{
+    static constexpr uint32_t kNR = NR;
+    alignas(16) unsigned char U[16u * NR];    // cut-point records from the bottom; the plane's stage and lists from the top
+    float4 planes[WC_MAXF];
+    uint16_t nlist[2][SURTR_WNL];             // alive cut points (ids) in creation order; the planes alternate between the two
+    uint16_t freel[SURTR_WNL];                // record units of cut points that are gone
+    uint32_t hist[WC_MAXF + 1], zhist[WC_MAXF + 1];
+    uint32_t bst[WC_MAXF + 2];                // first id of bucket k (bucket F: never clipped); bst[F + 1] = n
+    uint32_t wcnt[SURTR_NWAVE][WC_MAXF + 2];  // loader: originals per (wave, bucket)
+    uint32_t wsum[2][2 * SURTR_NWAVE];        // ordered scans: totals per wave (two sets, alternating)
+    uint32_t fl[3][2];                        // group-wide flags, three sets in rotation (see wc_any)
+    uint32_t zm[2];                           // planes some cut point lies in
+    uint32_t misc[8];
+#ifdef SURTR_STAMP
+    unsigned long long ph[32];
+#endif
+};
+typedef WcLdsT<SURTR_WR> WcLds;
+
+// The reduced Mesh of a pair as k_prep_pairs left it (ImgLayout, surtr_ctx.h).
+struct WcImg
+{
+    const uint16_t* loff; const uint8_t* llen; const uint8_t* fc; const uint16_t* ring; const float* pos;
+    const uint32_t* hist; const uint32_t* zhist; const uint32_t* nzero;
+    uint32_t n, hsum;
+};
+// Per-workgroup global scratch: the sorted records of the originals and their positions (n each), positions of the cut
+// points (by record unit).
+struct WcGlob { WcW4* grec; float4* gpos; float4* cpos; };
+__device__ __forceinline__ WcGlob wc_glob(char* slot, size_t slot_bytes, uint32_t n, uint32_t pool, bool& fits)
+{
+    WcGlob g;
+    const size_t nn = ((size_t)n + 15u) & ~(size_t)15u;
+    g.grec = (WcW4*)slot; g.gpos = (float4*)(slot + 16u * nn); g.cpos = (float4*)(slot + 32u * nn);
+    fits = 32u * nn + 16u * (size_t)pool <= slot_bytes;
+    return g;
+}
+
+// What the plane loop leaves for wc_park.
+struct WcOut { uint32_t nl, nLive, rtop, cur; };
+// Call counters of wc_any / wc_scan of one pair (uniform over the group).
+struct WcCtr { uint32_t ac, sc; };
+
+// Group-wide "does any thread say yes": one barrier.  Calls are numbered by the counter c (uniform); set c % 3 is written
+// before the barrier and read after it, set (c + 1) % 3 is cleared before the barrier -- its readers (call c - 2) are all past
+// the barrier of call c - 1, its writers (call c + 1) come after this one.
+template <class LT>
+__device__ __forceinline__ bool wc_any(LT& W, uint32_t& c, bool pred, uint32_t slot = 0u)
+{
+    if (threadIdx.x == 0u) { W.fl[(c + 1u) % 3u][0] = 0u; W.fl[(c + 1u) % 3u][1] = 0u; }
+    if (pred) W.fl[c % 3u][slot] = 1u;
+    __syncthreads();
+    const bool r = W.fl[c % 3u][slot] != 0u;
+    ++c;
+    return r;
+}
+
+// Ordered scan over items [0, N): every wave sweeps a contiguous range of 64-item blocks twice -- count(i) -> (a, b), then
+// place(i, exclusive a, exclusive b) -- with one barrier between the sweeps.  Returns the totals.  Every thread must call it;
+// sc: the pair's call counter (the per-wave totals alternate between two sets, so that no barrier is needed after it).
+template <class LT, class C1, class C2, class P>
+__device__ __forceinline__ uint2 wc_scan(LT& W, uint32_t& sc, uint32_t N, C1 count1, C2 count2, P place)
+{
+    const uint32_t lane = lane_id(), w = wave_id(), nw = group_waves();
+    const uint32_t nb = (N + SURTR_LANES - 1u) >> SURTR_LSH, nbw = (nb + nw - 1u) / nw;
+    const uint32_t b0 = w * nbw, b1 = b0 + nbw < nb ? b0 + nbw : nb;
+    uint32_t* ws = W.wsum[sc & 1u];
+    ++sc;
+    uint2 mine = make_uint2(0u, 0u);
+    for (uint32_t b = b0; b < b1; ++b)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        if (i < N) { const uint2 c = count1(i); mine.x += c.x; mine.y += c.y; }
+    }
+    const uint2 inc = wave_incl_scan2(mine);
+    if (lane == SURTR_LANES - 1u) { ws[2u * w] = inc.x; ws[2u * w + 1u] = inc.y; }
+    __syncthreads();
+    uint2 run = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
+    for (uint32_t q = 0; q < nw; ++q)
+    {
+        const uint32_t a = ws[2u * q], b = ws[2u * q + 1u];
+        if (q < w) { run.x += a; run.y += b; }
+        tot.x += a; tot.y += b;
+    }
+    for (uint32_t b = b0; b < b1; ++b)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        uint2 c = make_uint2(0u, 0u);
+        if (i < N) c = count2(i);
+        const uint2 s = wave_incl_scan2(c);
+        if (i < N) place(i, run.x + s.x - c.x, run.y + s.y - c.y);
+        run.x += lane_bcast(s.x, SURTR_LANES - 1u); run.y += lane_bcast(s.y, SURTR_LANES - 1u);
+    }
+    return make_uint2(SURTR_UNIFORM(tot.x), SURTR_UNIFORM(tot.y));
+}
+
+__device__ __forceinline__ uint32_t wc_popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
+
+// Sorts the band: stable counting sort by first clipping plane; records and positions of the originals go to the workgroup's
+// global scratch (g.grec / g.gpos, indexed by the sorted id).  The caller has put the cell's planes into W.planes.
+// Returns 0 or WC_BAIL (uniform); zmask = planes some band vertex lies in.
+template <class LT>
+__device__ __attribute__((always_inline)) inline int wc_load(LT& W, const WcImg im, const uint32_t F, const WcGlob g,
+                                                             unsigned long long& zmask, WcCtr& ctr, uint32_t* __restrict__ why)
+{
+    const uint32_t tid = threadIdx.x, lane = lane_id(), w = wave_id(), nw = group_waves();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned char* B = W.U;
+    const uint32_t n = im.n;
+    ctr.ac = 0u; ctr.sc = 0u;
+    // the id map (16 bits per band vertex) sits in LDS while the records are written
+    if (F > WC_MAXF || n == 0u || n >= WC_MAXN || n > 8u * LT::kNR) WC_RET(1);
+    const uint32_t tmp16 = 0u;
+    for (uint32_t k = tid; k < nw * (WC_MAXF + 2u); k += group_size()) (&W.wcnt[0][0])[k] = 0u;
+    for (uint32_t k = tid; k < F; k += group_size()) { W.hist[k] = im.hist[k]; W.zhist[k] = im.zhist[k]; }
+    if (tid == 0u) { W.zm[0] = 0u; W.zm[1] = 0u; for (int q = 0; q < 6; ++q) (&W.fl[0][0])[q] = 0u; }
+    unsigned long long zm = 0ull;
+    for (uint32_t k0 = 0; k0 < F; k0 += SURTR_LANES)
+    {
+        const uint32_t k = k0 + lane;
+        zm |= __ballot(k < F && im.nzero[k] != 0u) << k0;
+    }
+    zmask = zm;
+    // (conservative: a plane an original lies in might never be reached; the general clipper decides)
+    if (zm != 0ull) WC_RET(17);
+    __syncthreads();
+    WSTAMP_DECL;
+    // every wave takes a contiguous range of the band (in 64-vertex blocks): vertices per bucket, then ranks
+    const uint32_t nb = (n + SURTR_LANES - 1u) >> SURTR_LSH, nbw = (nb + nw - 1u) / nw;
+    const uint32_t bb0 = w * nbw, bb1 = bb0 + nbw < nb ? bb0 + nbw : nb;
+    bool odd = false;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+        for (uint32_t bb = bb0; bb < bb1; ++bb)
+        {
+            const uint32_t b = (bb << SURTR_LSH) + lane;
+            const bool valid = b < n;
+            const uint32_t f = valid ? (uint32_t)im.fc[b] : 0u;
+            uint32_t bk = f == SURTR_NEVER ? F : f;
+            if (valid && pass == 0 && (bk > F || (uint32_t)im.llen[b] > 7u)) odd = true;
+            if (bk > F) bk = F;
+            unsigned long long todo = __ballot(valid);
+            uint32_t sid = 0;
+            while (todo)
+            {
+                const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                const uint32_t k0 = lane_bcast(bk, leader);
+                const unsigned long long same = __ballot(valid && bk == k0);
+                uint32_t base = 0;
+                if (lane == leader) { base = W.wcnt[w][k0]; W.wcnt[w][k0] = base + wc_popc64(same); }      // (this wave's own row)
+                base = lane_bcast(base, leader);
+                if (valid && bk == k0) sid = base + wc_popc64(same & lt);
+                todo &= ~same;
+            }
+            if (valid && pass == 1) wc_st16(B, tmp16 + b, sid);
+        }
+        if (pass == 1) break;
+        __syncthreads();
+        // bucket starts, and in every wave's row the first id it hands out per bucket
+        if (w == 0u)
+        {
+            uint32_t carry = 0;
+            for (uint32_t k0 = 0; k0 <= F; k0 += SURTR_LANES)
+            {
+                const uint32_t k = k0 + lane;
+                uint32_t c = 0;
+                if (k <= F) for (uint32_t q = 0; q < nw; ++q) c += W.wcnt[q][k];
+                const uint32_t inc = wave_incl_scan2(make_uint2(c, 0u)).x;
+                if (k <= F)
+                {
+                    uint32_t at = carry + inc - c;
+                    W.bst[k] = at;
+                    for (uint32_t q = 0; q < nw; ++q) { const uint32_t cq = W.wcnt[q][k]; W.wcnt[q][k] = at; at += cq; }
+                }
+                carry += lane_bcast(inc, SURTR_LANES - 1u);
+            }
+            if (lane == 0u) W.bst[F + 1u] = carry;
+        }
+        __syncthreads();
+    }
+    if (wc_any(W, ctr.ac, odd)) WC_RET(2);
+    WSTAMP(0);
+    for (uint32_t b = tid; b < n; b += group_size())
+    {
+        const uint32_t sid = wc_ld16(B, tmp16 + b);
+        const uint32_t lo = im.loff[b], len = im.llen[b], f = im.fc[b];
+        uint32_t e[7];
+#pragma unroll
+        for (uint32_t q = 0; q < 7u; ++q) e[q] = im.ring[lo + (q < len ? q : 0u)];
+#pragma unroll
+        for (uint32_t q = 0; q < 7u; ++q)
+        {
+            const uint32_t m = wc_ld16(B, tmp16 + (e[q] < n ? e[q] : 0u));
+            e[q] = q >= len ? WC_NONE : (e[q] < n ? m : WC_SENT);
+        }
+        WcW4 wr;
+        wr.a = e[0] | (e[1] << 16); wr.b = e[2] | (e[3] << 16); wr.c = e[4] | (e[5] << 16); wr.d = e[6] | ((f | (len << 8)) << 16);
+        g.grec[sid] = wr;
+        g.gpos[sid] = make_float4(im.pos[3u * b], im.pos[3u * b + 1u], im.pos[3u * b + 2u], 0.f);
+    }
+    __syncthreads();
+    WSTAMP(1);
+    WCOUNT(16, 1); WCOUNT(17, n);
+    return 0;
+}
+
+// The plane loop.  Returns 0 (out.nLive == 0: nothing is left) or WC_BAIL.
+template <class LT>
+__device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint32_t F, const uint32_t n, const uint32_t dropTotal, unsigned long long zmask,
+                                                               const WcGlob g, const uint32_t capPool, WcOut& out, WcCtr& ctr, uint32_t* __restrict__ why)
+{
+    const uint32_t tid = threadIdx.x, G = group_size();
+    unsigned char* B = W.U;
+    unsigned char* GB = (unsigned char*)g.grec;               // (16-bit patches of original records)
+    uint32_t rtop = 0, nl = 0, nLive = n, cur = 0, nfree = 0;  // cut-point records in use from the bottom; free-list length
+    uint32_t ac = ctr.ac, sc = ctr.sc;
+    out.nl = 0; out.nLive = 0; out.rtop = 0; out.cur = 0;
+    WSTAMP_DECL;
+    for (uint32_t k = 0; k < F; ++k)
+    {
+        if ((zmask >> k) & 1ull) WC_RET(3);          // a live vertex lies in this plane: the reference's general relink
+        const float4 pl = W.planes[k];
+        // originals this plane clips: ids [b0, b1), in order; later buckets are kept, earlier ones gone
+        const uint32_t b0 = SURTR_UNIFORM(W.bst[k]), b1 = SURTR_UNIFORM(W.bst[k + 1u]);
+        const uint32_t nCo = b1 - b0;
+        uint32_t ltop = 8u * LT::kNR;                     // stage and lists are carved downwards from the top (16-bit word index, 16-byte steps)
+        auto carve = [&](uint32_t cnt16) -> uint32_t { ltop -= (cnt16 + 7u) & ~7u; return ltop; };
+        if (4u * rtop + 8u * nCo + nl + 64u > ltop) WC_RET(4);
+        // ---- stage: this plane's originals into LDS (their records are final: every patch of an earlier plane is in) ----
+        const uint32_t stage = carve(8u * nCo) / 8u;      // first unit of the stage
+        for (uint32_t i = tid; i < nCo; i += G)
+        {
+            const WcW4 wr = g.grec[b0 + i];
+            __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16);
+        }
+        // where the record of a vertex that is in LDS sits: a cut point (pool, 8-byte units from the bottom) or an original of this
+        // plane (stage); t16_of: 16-bit word index of its tail
+        auto off_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 8u * (e - WC_MAXN) : 16u * (stage + (e - b0)); };
+        auto t16_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 4u * (e - WC_MAXN) + 3u : 8u * (stage + (e - b0)) + 7u; };
+        auto rec_of = [&](uint32_t e) -> WcRec { return wc_rec(B, off_of(e), e >= WC_MAXN); };
+        // ---- the clipped cut points (first clipping plane == k), in creation order; the others move to the other nlist, in order ----
+        const uint32_t cnew = carve(nl);
+        const uint16_t* nin = W.nlist[cur]; uint16_t* nout = W.nlist[cur ^ 1u];
+        auto nfl = [&](uint32_t i) -> uint2 { const bool c = (wc_ld16(B, 4u * ((uint32_t)nin[i] - WC_MAXN) + 3u) & 0xFFu) == k; return make_uint2(c ? 1u : 0u, c ? 0u : 1u); };
+        const uint2 nt = wc_scan(W, sc, nl, nfl, nfl, [&](uint32_t i, uint32_t xc, uint32_t xk) {
+            const uint32_t e = nin[i];
+            if ((wc_ld16(B, 4u * (e - WC_MAXN) + 3u) & 0xFFu) == k) wc_st16(B, cnew + xc, e); else nout[xk] = (uint16_t)e;
+        });
+        const uint32_t nCn = nt.x, keepn = nt.y;
+        cur ^= 1u;
+        __syncthreads();
+        WSTAMP(2);
+        const uint32_t nC = nCo + nCn;
+        const uint32_t dropAlive = SURTR_UNIFORM(W.hist[k]);
+        const uint32_t dropKept = dropAlive - SURTR_UNIFORM(W.zhist[k]);      // dropped vertices strictly on the kept side
+        if (nLive <= nC && dropKept == 0u)
+        {
+            if (nC == 0u) WC_RET(5);                 // every vertex in the plane: the bounding-box rule (:296-299) of the general clipper
+            nLive = 0; break;                             // "below": everything goes (:322-327)
+        }
+        if (nC == 0u)
+        {
+            nl = keepn;
+            if (nLive + dropAlive < 4u) { nLive = 0; break; }      // (:497-499)
+            continue;
+        }
+        if (nC > 4095u) WC_RET(6);
+        // ---- kept neighbours of every clipped vertex (bit j = ring slot j), number of its first new vertex ----
+        if (4u * rtop + 2u * nC + 32u > ltop) WC_RET(7);
+        const uint32_t cbase = carve(nC), ckm8 = 2u * carve((nC + 1u) / 2u);      // ckm8: byte index
+        auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : wc_ld16(B, cnew + (i - nCo)); };
+        bool bad = false;
+        const uint2 mt = wc_scan(W, sc, nC,
+            [&](uint32_t i) -> uint2 {
+                const WcRec r = rec_of(clipped_id(i));
+                // the first clipping plane of every cut point among the neighbours: all seven loads in flight together
+                uint32_t ee[7], tl[7];
+#pragma unroll
+                for (uint32_t q = 0; q < 7u; ++q) ee[q] = r.e(q);
+#pragma unroll
+                for (uint32_t q = 0; q < 7u; ++q) tl[q] = wc_ld16(B, (ee[q] >= WC_MAXN && ee[q] < WC_SENT) ? 4u * (ee[q] - WC_MAXN) + 3u : 3u);
+                uint32_t km = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < 7u; ++q)
+                {
+                    // an original is kept when it sits in a later bucket, a cut point when its own first clipping plane is later;
+                    // a dropped vertex (WC_SENT) goes with this plane
+                    const bool kept = ee[q] < WC_MAXN ? ee[q] >= b1 : (ee[q] < WC_SENT && (tl[q] & 0xFFu) > k);
+                    if (kept) km |= 1u << q;
+                }
+                // a ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354)
+                if (km & (km - 1u))
+                {
+#pragma unroll
+                    for (uint32_t q = 1; q < 7u; ++q)
+#pragma unroll
+                        for (uint32_t q2 = 0; q2 < q; ++q2)
+                            if (((km >> q) & 1u) && ((km >> q2) & 1u) && ee[q] == ee[q2]) bad = true;
+                }
+                wc_st8(B, ckm8 + i, km);
+                return make_uint2((uint32_t)__builtin_popcount(km), 0u);
+            },
+            [&](uint32_t i) -> uint2 { return make_uint2((uint32_t)__builtin_popcount(wc_ld8(B, ckm8 + i)), 0u); },
+            [&](uint32_t i, uint32_t xm, uint32_t) { wc_st16(B, cbase + i, xm); });
+        const uint32_t M = mt.x;
+        if (wc_any(W, ac, bad)) WC_RET(8);
+        if (M > 4095u || keepn + M > SURTR_WNL || nfree + nCn > SURTR_WNL) WC_RET(9);
+        if (4u * rtop + 3u * M + 2u * nC + 64u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
+        const uint32_t src = carve(M), wst = carve(M), xid = carve(M), nd = carve(2u * nC);
+        // ---- record units of the new vertices: those of cut points that are gone first, then the end of the pool ----
+        {
+            const uint32_t fromf = nfree < M ? nfree : M, fromt = M - fromf;
+            const uint32_t room = ltop / 4u > rtop ? ltop / 4u - rtop : 0u;
+            if (fromt > room || rtop + fromt > capPool) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(16); }
+            for (uint32_t t = tid; t < M; t += G) wc_st16(B, xid + t, WC_MAXN + (t < fromf ? (uint32_t)W.freel[nfree - 1u - t] : rtop + (t - fromf)));
+            nfree -= fromf; rtop += fromt;
+        }
+        WSTAMP(3);
+        WCOUNT(18, 1); WCOUNT(19, nC); WCOUNT(20, M); WCOUNT(21, nl);
+#ifdef SURTR_STAMP
+        if (tid == 0u) { const unsigned long long need = 2ull * (4u * rtop + (8u * LT::kNR - ltop)); if (need > W.ph[31]) W.ph[31] = need; if (k < 2u) { if (need > W.ph[30]) W.ph[30] = need; } else if (need > W.ph[29]) W.ph[29] = need; }
+#endif
+        // ---- every clipped vertex gets its position in the list into its tail; source (clipped vertex, slot) of every new
+        //      vertex, in the reference's order (:333-357) ----
+        for (uint32_t i = tid; i < nC; i += G)
+        {
+            const uint32_t km = wc_ld8(B, ckm8 + i);
+            uint32_t t = wc_ld16(B, cbase + i);
+            const uint32_t t16 = t16_of(clipped_id(i));
+            const uint32_t tl = wc_ld16(B, t16);
+            wc_st16(B, t16, 0x8000u | (((tl >> 8) & 7u) << 12) | i);
+            for (uint32_t m = km; m; m &= m - 1u, ++t) wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12));
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < M; t += G) wc_st16(B, 4u * (wc_ld16(B, xid + t) - WC_MAXN), WC_NONE);      // predecessor: not yet known
+        // the cut points this plane clips are gone after it: their units go to the free list (nobody takes from it before the next plane)
+        for (uint32_t i = tid; i < nCn; i += G) W.freel[nfree + i] = (uint16_t)(wc_ld16(B, cnew + i) - WC_MAXN);
+        nfree += nCn;
+        WSTAMP(4);
+        // ---- successor of every new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j,
+        //      and so on through clipped vertices, until the entry is a kept vertex -- the new vertex on that edge (:367-425) ----
+        const uint32_t nref = nLive + (k ? SURTR_UNIFORM(W.hist[k - 1u]) : dropTotal) + M;      // the reference's walk bound (:389-394)
+        bool fail = false;
+        // state of a walk: at clipped vertex cv (position pcv in the clipped list, record rc) about to take ring slot p.
+        // Returns the number of the new vertex it ends on, WC_NONE when it pauses after `limit` steps (or fails).
+        auto walk = [&](uint32_t& cv, uint32_t& pcv, uint32_t& p, WcRec& rc, uint32_t& steps, const uint32_t limit, const bool jump) -> uint32_t {
+            while (true)
+            {
+                if (jump && p == 0u)
+                {
+                    // a run of clipped vertices each entered through its slot 1 and left through its slot 0: the pointer
+                    // jumping below collapsed it (clip_core.h does the same for its resumed walks)
+                    const uint32_t a = wc_ld32(B, nd + 2u * pcv), jx = a & 0xFFFFu;
+                    if (jx != pcv) { pcv = jx; cv = clipped_id(jx); steps += a >> 16; rc = rec_of(cv); }
+                }
+                const uint32_t kmc = wc_ld8(B, ckm8 + pcv);
+                if ((kmc >> p) & 1u) return wc_ld16(B, cbase + pcv) + (uint32_t)__builtin_popcount(kmc & ((1u << p) - 1u));
+                if (steps >= limit) return WC_NONE;
+                const uint32_t e = rc.e(p);
+                // the next vertex must be one this plane clips: an original of its bucket or a cut point (checked by its tail)
+                if (e >= WC_SENT || (e < WC_MAXN && (e < b0 || e >= b1)) || steps + 2u >= nref)
+                { SURTR_DBG("  wc walk: sentinel / not clipped / bound e=%u steps=%u nref=%u k=%u\n", e, steps, nref, k); fail = true; return WC_NONE; }
+                ++steps;
+                const WcRec re = rec_of(e);
+                const uint32_t te = re.tail();
+                if (!(te & 0x8000u)) { SURTR_DBG("  wc walk: vertex %u not clipped now (tail %x) k=%u\n", e, te, k); fail = true; return WC_NONE; }
+                const uint32_t le = (te >> 12) & 7u, q = re.find(cv, le);
+                if (q >= le) { SURTR_DBG("  wc walk: no way back k=%u\n", k); fail = true; return WC_NONE; }
+                p = q ? q - 1u : le - 1u; cv = e; pcv = te & 0xFFFu; rc = re;
+            }
+        };
+        bool paused = false;
+        for (uint32_t t = tid; t < M; t += G)
+        {
+            const uint32_t s = wc_ld16(B, src + t);
+            uint32_t pcv = s & 0xFFFu, cv = clipped_id(pcv);
+            const uint32_t j = s >> 12;
+            WcRec rc = rec_of(cv);
+            const uint32_t lv = (rc.tail() >> 12) & 7u;
+            uint32_t p = j ? j - 1u : lv - 1u, steps = 0;
+            const uint32_t end = walk(cv, pcv, p, rc, steps, SURTR_WWALK0, false);
+            if (end != WC_NONE) wc_st16(B, wst + t, 0x8000u | end);
+            else { wc_st16(B, wst + t, pcv | (p << 12)); paused = true; }
+        }
+        const bool anyPaused = wc_any(W, ac, paused, 0u);
+        WSTAMP(5);
+        if (anyPaused)
+        {
+            WCOUNT(24, 1);
+            // nd[i] = (where the walk that stands on clipped vertex i, about to take its slot 0, gets to along its run | steps):
+            // it moves on to e0 whenever slot 0 holds no kept vertex, and is there about to take slot 0 again when it arrives
+            // through e0's slot 1
+            for (uint32_t i = tid; i < nC; i += G)
+            {
+                const uint32_t c = clipped_id(i);
+                const WcRec r = rec_of(c);
+                const uint32_t e0 = r.e(0u);
+                uint32_t nx = i, d = 0;
+                if (!(wc_ld8(B, ckm8 + i) & 1u) && e0 < WC_SENT && (e0 >= WC_MAXN || (e0 >= b0 && e0 < b1)))
+                {
+                    const WcRec r0 = rec_of(e0);
+                    const uint32_t t0 = r0.tail();
+                    if ((t0 & 0x8000u) && r0.find(c, (t0 >> 12) & 7u) == 1u) { nx = t0 & 0xFFFu; d = 1u; }
+                }
+                wc_st32(B, nd + 2u * i, nx | (d << 16));
+            }
+            __syncthreads();
+            for (uint32_t round = 0; round < 12u; ++round)
+            {
+                bool ch = false;
+                for (uint32_t i = tid; i < nC; i += G)
+                {
+                    const uint32_t a = wc_ld32(B, nd + 2u * i), j1 = a & 0xFFFFu;
+                    if (j1 == i) continue;
+                    const uint32_t b2 = wc_ld32(B, nd + 2u * j1), j2 = b2 & 0xFFFFu;
+                    if (j2 != j1) { wc_st32(B, nd + 2u * i, j2 | (((a >> 16) + (b2 >> 16)) << 16)); ch = true; }
+                }
+                if (!wc_any(W, ac, ch, 0u)) break;
+            }
+            WSTAMP(6);
+            for (uint32_t t = tid; t < M; t += G)
+            {
+                const uint32_t ws = wc_ld16(B, wst + t);
+                if (ws & 0x8000u) continue;
+                uint32_t pcv = ws & 0xFFFu, cv = clipped_id(pcv), p = ws >> 12, steps = SURTR_WWALK0;
+                WcRec rc = rec_of(cv);
+                const uint32_t end = walk(cv, pcv, p, rc, steps, 0xFFFFFFFFu, true);
+                if (end != WC_NONE) wc_st16(B, wst + t, 0x8000u | end);
+                else fail = true;
+#ifdef SURTR_STAMP
+                atomicAdd(&g_wstamp[22], (unsigned long long)steps); atomicMax(&g_wstamp[23], (unsigned long long)steps);      // (rare: resumed walks only)
+#endif
+            }
+            WSTAMP(7);
+        }
+        if (wc_any(W, ac, fail, 1u)) WC_RET(11);
+        WSTAMP(25);
+        // ---- the new vertices: position, first clipping plane, record [pred, succ, kept end], back-link of the kept end ----
+        uint32_t myz0 = 0, myz1 = 0;
+        uint16_t* nnow = W.nlist[cur];
+        for (uint32_t t = tid; t < M; t += G)
+        {
+            const uint32_t s = wc_ld16(B, src + t), end = wc_ld16(B, wst + t) & 0xFFFu;
+            const uint32_t v = clipped_id(s & 0xFFFu), j = s >> 12;
+            const uint32_t X = wc_ld16(B, xid + t), Z = wc_ld16(B, xid + end);
+            const WcRec r = rec_of(v);
+            const uint32_t u = r.e(j);
+            const float4 pa = v < WC_MAXN ? g.gpos[v] : g.cpos[v - WC_MAXN];
+            const float4 pb = u < WC_MAXN ? g.gpos[u] : g.cpos[u - WC_MAXN];
+            // the kept end: an original lives in global memory, a cut point in LDS
+            WcRec ru;
+            if (u < WC_MAXN) { const WcW4 wr = g.grec[u]; ru = WcRec{wr.a, wr.b, wr.c, wr.d}; } else ru = wc_rec(B, 8u * (u - WC_MAXN), true);
+            if (end == t) { SURTR_DBG("  wc walk: ends on itself k=%u\n", k); fail = true; continue; }
+            const uint32_t ux = X - WC_MAXN, uz = Z - WC_MAXN;
+            wc_st16(B, 4u * uz, X);                                                // X is the predecessor of Z
+            // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
+            const float sa = plane_dist(pl, pa.x, pa.y, pa.z), sb = plane_dist(pl, pb.x, pb.y, pb.z);
+            const float inv = 1.f / (sb - sa);
+            const float nx = (pa.x * sb - pb.x * sa) * inv, ny = (pa.y * sb - pb.y * sa) * inv, nz = (pa.z * sb - pb.z * sa) * inv;
+            g.cpos[ux] = make_float4(nx, ny, nz, 0.f);
+            uint32_t f = SURTR_NEVER;
+            for (uint32_t q = k + 1u; q < F; ++q)
+            {
+                const int cq = side_of(plane_dist(W.planes[q], nx, ny, nz));
+                if (cq < 0) { f = q; break; }
+                if (cq == 0) { if (q < 32u) myz0 |= 1u << q; else myz1 |= 1u << (q - 32u); }
+            }
+            // the record but for its slot 0, which the walk that ends on X writes
+            wc_st16(B, 4u * ux + 1u, Z);
+            wc_st32(B, 4u * ux + 2u, u | ((f | (3u << 8)) << 16));
+            nnow[keepn + t] = (uint16_t)X;
+            // the kept end now links X instead of v (:350-354: first occurrence)
+            const uint32_t tu = ru.tail(), qu = ru.find(v, (tu >> 8) & 7u);
+            if ((tu & 0x8000u) || qu >= ((tu >> 8) & 7u)) { SURTR_DBG("  wc patch: kept end does not link the clipped vertex k=%u\n", k); fail = true; continue; }
+            if (u < WC_MAXN) { const uint16_t xv = (uint16_t)X; __builtin_memcpy(GB + 16u * (size_t)u + 2u * qu, &xv, 2); }
+            else wc_st16(B, 4u * (u - WC_MAXN) + qu, X);
+        }
+        if (myz0) atomicOr(&W.zm[0], myz0);
+        if (myz1) atomicOr(&W.zm[1], myz1);
+        __syncthreads();
+        WSTAMP(8);
+        // every new vertex must be the successor of exactly one other (a cap of two vertices gives rings [Z, Z, kept], as in the
+        // reference; a later plane that meets such a ring at a clipped vertex finds it in the doubled-neighbour test above)
+        for (uint32_t t = tid; t < M && !fail; t += G)
+        {
+            const uint32_t X = wc_ld16(B, xid + t), Z = wc_ld16(B, xid + (wc_ld16(B, wst + t) & 0xFFFu));
+            if (wc_ld16(B, 4u * (X - WC_MAXN)) == WC_NONE || Z == X || wc_ld16(B, 4u * (Z - WC_MAXN)) != X) { SURTR_DBG("  wc check: X=%u succ=%u k=%u M=%u\n", X, Z, k, M); fail = true; }
+        }
+        if (wc_any(W, ac, fail, 1u)) WC_RET(11);
+        zmask |= (unsigned long long)SURTR_UNIFORM(W.zm[0]) | ((unsigned long long)SURTR_UNIFORM(W.zm[1]) << 32);
+        nLive = nLive - nC + M; nl = keepn + M;
+        WSTAMP(9);
+        if (nLive + dropAlive < 4u) { nLive = 0; break; }                          // (:497-499)
+    }
+    __syncthreads();
+    out.nl = nl; out.nLive = nLive; out.rtop = rtop; out.cur = cur;
+    ctr.ac = ac; ctr.sc = sc;
+    return 0;
+}
+
+// Islands of what is left (CheckMeshIsland, Src/Surtr.cpp:2157-2201) + the island-major copy to the arena (:1474-1500):
+// what park_mesh_islands does for a Topo.  Returns 0, SURTR_E_CAPACITY or WC_BAIL.
+template <class LT, class AR, class PR>
+__device__ __attribute__((always_inline)) inline int wc_park(LT& W, const uint32_t F, const uint32_t n, const WcOut o, const WcGlob g,
+                                                             const AR& A, PR& rec, WcCtr& ctr, uint32_t* __restrict__ why)
+{
+    const uint32_t tid = threadIdx.x, G = group_size(), lane = lane_id();
+    unsigned char* B = W.U;
+    const uint32_t bN = SURTR_UNIFORM(W.bst[F]);
+    const uint32_t nOn = n - bN, nA = nOn + o.nl;
+    const uint16_t* nlist = W.nlist[o.cur];
+    uint32_t ac = ctr.ac, sc = ctr.sc;
+    if (nA != o.nLive || nA >= 4096u) WC_RET(12);
+    uint32_t ltop = 8u * LT::kNR;
+    auto carve = [&](uint32_t cnt16) -> uint32_t { ltop -= (cnt16 + 7u) & ~7u; return ltop; };
+    if (4u * o.rtop + 5u * (nA + 8u) > ltop) WC_RET(13);
+    const uint32_t clen = carve(nA), coff = carve(nA), lab = carve(nA), local = carve(nA), olo = carve(nA);
+    // packed index of a survivor: originals by their place in the never-clipped bucket, cut points behind them in creation
+    // order (their tail holds it from here on)
+    auto idof = [&](uint32_t i) -> uint32_t { return i < nOn ? bN + i : (uint32_t)nlist[i - nOn]; };
+    auto recof = [&](uint32_t id) -> WcRec { if (id < WC_MAXN) { const WcW4 wr = g.grec[id]; return WcRec{wr.a, wr.b, wr.c, wr.d}; } return wc_rec(B, 8u * (id - WC_MAXN), true); };
+    for (uint32_t i = tid; i < o.nl; i += G) wc_st16(B, 4u * ((uint32_t)nlist[i] - WC_MAXN) + 3u, 0x4000u | (nOn + i));
+    WSTAMP_DECL;
+    auto lenfn = [&](uint32_t i) -> uint2 { return make_uint2(i < nOn ? (g.grec[bN + i].d >> 24) & 7u : 3u, 0u); };
+    const uint32_t H = wc_scan(W, sc, nA, lenfn, lenfn, [&](uint32_t i, uint32_t xo, uint32_t) {
+        wc_st16(B, clen + i, lenfn(i).x); wc_st16(B, coff + i, xo); wc_st16(B, lab + i, i); }).x;
+    if (H >= 0xFFFFu || 4u * o.rtop + H + 16u > ltop) WC_RET(14);
+    const uint32_t cring = carve(H);
+    __syncthreads();
+    WSTAMP(10);
+    bool odd = false;
+    for (uint32_t i = tid; i < nA; i += G)
+    {
+        const WcRec r = recof(idof(i));
+        const uint32_t off = wc_ld16(B, coff + i), len = wc_ld16(B, clen + i);
+        for (uint32_t q = 0; q < len; ++q)
+        {
+            const uint32_t e = r.e(q);
+            uint32_t rk = 0;
+            if (e < WC_MAXN) { if (e < bN || e >= n) odd = true; else rk = e - bN; }
+            else if (e >= WC_SENT) odd = true;
+            else { const uint32_t te = wc_ld16(B, 4u * (e - WC_MAXN) + 3u); if ((te & 0xC000u) != 0x4000u) odd = true; rk = te & 0xFFFu; }
+            if (rk >= nA) { odd = true; rk = 0; }
+            wc_st16(B, cring + off + q, rk);
+        }
+    }
+    if (wc_any(W, ac, odd)) WC_RET(15);             // a survivor links a vertex that is gone: not a regular result
+    WSTAMP(11);
+    // min-label propagation with one pointer jump per round: labels end as the lowest vertex of the island
+    while (true)
+    {
+        bool ch = false;
+        for (uint32_t i = tid; i < nA; i += G)
+        {
+            const uint32_t mine = wc_ld16(B, lab + i), off = wc_ld16(B, coff + i), len = wc_ld16(B, clen + i);
+            uint32_t m = mine;
+            for (uint32_t q = 0; q < len; ++q) { const uint32_t l2 = wc_ld16(B, lab + wc_ld16(B, cring + off + q)); m = l2 < m ? l2 : m; }
+            const uint32_t mm = wc_ld16(B, lab + m);
+            m = mm < m ? mm : m;
+            if (m < mine) { wc_st16(B, lab + i, m); ch = true; }
+        }
+        if (!wc_any(W, ac, ch)) break;
+    }
+    WSTAMP(12);
+    auto rootfn = [&](uint32_t i) -> uint2 { return make_uint2(wc_ld16(B, lab + i) == i ? 1u : 0u, 0u); };
+    const uint32_t ni = wc_scan(W, sc, nA, rootfn, rootfn, [&](uint32_t, uint32_t, uint32_t) {}).x;
+    __syncthreads();
+    if (tid == 0u) { W.misc[0] = atomicAdd(&A.cursors[0], nA); W.misc[1] = atomicAdd(&A.cursors[1], H); W.misc[2] = atomicAdd(&A.cursors[3], ni); }
+    __syncthreads();
+    const uint32_t voff = W.misc[0], hoff = W.misc[1], ioff = W.misc[2];
+    ctr.ac = ac; ctr.sc = sc;
+    if ((uint64_t)voff + nA > A.capV || (uint64_t)hoff + H > A.capH || (uint64_t)ioff + ni > A.capIsl) return SURTR_E_CAPACITY;
+    // islands in order of their lowest vertex; inside an island the vertices keep their order (std::set, :1482-1492)
+    uint32_t vbase = 0, hbase = 0, root = 0;
+    for (uint32_t t = 0; t < ni; ++t)
+    {
+        // the next root at or after `root` (every wave looks for itself: the labels are final)
+        while (root < nA)
+        {
+            const uint32_t i = root + lane;
+            const unsigned long long m = __ballot(i < nA && wc_ld16(B, lab + i) == i);
+            if (m) { root += (uint32_t)__builtin_ctzll(m); break; }
+            root += SURTR_LANES;
+        }
+        auto infn = [&](uint32_t i) -> uint2 { const bool in = wc_ld16(B, lab + i) == root; return make_uint2(in ? 1u : 0u, in ? wc_ld16(B, clen + i) : 0u); };
+        const uint2 tt = wc_scan(W, sc, nA, infn, infn, [&](uint32_t i, uint32_t lv, uint32_t lh) {
+            if (wc_ld16(B, lab + i) != root) return;
+            wc_st16(B, local + i, lv); wc_st16(B, olo + i, lh);
+            const size_t dv = (size_t)voff + vbase + lv;
+            const uint32_t id = idof(i);
+            const float4 p = id < WC_MAXN ? g.gpos[id] : g.cpos[id - WC_MAXN];
+            A.pos[3u * dv] = p.x; A.pos[3u * dv + 1u] = p.y; A.pos[3u * dv + 2u] = p.z;
+            A.llen[dv] = wc_ld16(B, clen + i); A.loff[dv] = hoff + hbase + lh;
+        });
+        if (tid == 0u) A.isl[ioff + t] = tt;
+        __syncthreads();
+        for (uint32_t i = tid; i < nA; i += G)
+        {
+            if (wc_ld16(B, lab + i) != root) continue;
+            const uint32_t off = wc_ld16(B, coff + i), len = wc_ld16(B, clen + i);
+            int32_t* d = A.nbr + (size_t)hoff + hbase + wc_ld16(B, olo + i);
+            for (uint32_t q = 0; q < len; ++q) d[q] = (int32_t)wc_ld16(B, local + wc_ld16(B, cring + off + q));
+        }
+        vbase += tt.x; hbase += tt.y; root += 1u;
+        __syncthreads();
+    }
+    ctr.sc = sc;
+    rec.mv_off = voff; rec.mv_n = nA; rec.mh_off = hoff; rec.mh_n = H; rec.ni = ni; rec.isl_off = ioff;
+    WSTAMP(13);
+    return 0;
+}
+
+} // namespace surtr
