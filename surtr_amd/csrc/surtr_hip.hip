@@ -869,6 +869,9 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                  __builtin_popcount(sh.cutmask[2]) + __builtin_popcount(sh.cutmask[3]));
                 const uint32_t cost = (41u * ncut + n / 40u) / 110u;
                 cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (cost < 11u ? cost : 11u);
+                // a band vertex lies in a plane: the record clipper hands the pair to the general clipper, which takes longer --
+                // such pairs go first (the top regular class), not into the tail of the queue
+                if (cls < 12u) { bool inplane = false; for (uint32_t k = 0; k < F; ++k) if (sh.nzero[k] != 0u) inplane = true; if (inplane) cls = 12u; }
             }
             // k_clip_pairs_big has a few dozen workgroups: on a mesh whose bands outgrow the regular topology as a rule (some
             // 100 000 vertices) it takes the first `big_quota` such pairs and the regular kernel's workgroups do the others on
@@ -959,6 +962,75 @@ __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t p
     return err;
 }
 
+// One pair through the general clipper: image (or pre-pass) -> plane loop -> islands -> arena, with the global-scratch and
+// literal fallbacks.  rec: the pair's record as k_clip_convex / k_prep_pairs left it; stores pairs[p] unless the pair was handed
+// to the half table's retry list.  Every thread of the group must call it.
+template <bool HALF = false, class LT>
+__device__ __attribute__((always_inline)) static inline void clip_pair_general(Shared& sh, LT& L, Scratch& S, const ScratchPool& pool, uint32_t wg, const Pieces& P,
+                                       const float4* __restrict__ planes, const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                       const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                       uint32_t* __restrict__ horder, const uint32_t p, PairRec rec)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
+    const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
+    const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
+    for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
+    __syncthreads();
+    const uint32_t m0 = P.mvo[piece];
+    SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
+                P.mperm + m0, P.mposr_s + m0, P.mbsph + P.mbo[piece]};
+    auto consume = [&](auto& T) -> int {
+        if (T.nLive == 0) return 0;
+        return park_mesh_islands(T, sh, A, rec);
+    };
+    if (P.mdup[piece] != 0 && min.nv <= SURTR_LITERAL_START_V)
+    {
+        // a sliver Mesh (a few vertices, a ring lists a neighbour twice): literal clipper from the start (see pair_global) --
+        // on the regular kernel's scratch (the half-size kernel's has no room for it: its retry list).  A larger Mesh with
+        // such a ring keeps the parallel clipper (one lane would take milliseconds for it) and falls back only on an error.
+        if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }
+        else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
+        return;
+    }
+    int err;
+    if (HALF)
+    {
+        // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
+        // (class 0), which a second launch of k_clip_pairs picks up
+        if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, 0u, min, F, S, sh, L, consume);
+        else err = clip_any<false>(min, F, S, sh, L, consume);
+        __syncthreads();
+        if (err == SURTR_OVERFLOW)
+        {
+            if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p;
+            return;
+        }
+    }
+    else
+    {
+        err = SURTR_OVERFLOW;
+        if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, rec.img_pc, min, F, S, sh, L, consume);
+        else if (rec.img_fmt != IMG_WIDE) err = clip_any<false>(min, F, S, sh, L, consume);
+        __syncthreads();
+        if (err == SURTR_OVERFLOW)
+        {
+            pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 0u);
+            return;
+        }
+    }
+    if (err == SURTR_E_TOPOLOGY && min.nv <= SURTR_LITERAL_MESH_V)
+    {
+        __syncthreads();
+        if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }       // (the regular kernel redoes the pair: see above)
+        else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
+        return;
+    }
+    if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
+    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+    if (tid == 0) pairs[p] = rec;
+}
+
 template <bool HALF = false, class LT>
 __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Shared& sh, LT& L, const ScratchPool& pool, uint32_t wg, const Pieces& P, const float4* __restrict__ planes,
                                        const uint32_t* __restrict__ plane_off, uint32_t cell_begin, uint32_t n_pairs,
@@ -1006,67 +1078,9 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
 #endif
-        const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
-        const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
-        const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
-        for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
-        __syncthreads();
-        const uint32_t m0 = P.mvo[piece];
-        SolidIn min{P.mpos + 3 * (size_t)m0, P.mloff + m0, P.mllen + m0, P.mnbr, P.mvo[piece + 1] - m0, P.mtri + m0, P.mrad + m0,
-                    P.mperm + m0, P.mposr_s + m0, P.mbsph + P.mbo[piece]};
-        auto consume = [&](auto& T) -> int {
-            if (T.nLive == 0) return 0;
-            return park_mesh_islands(T, sh, A, rec);
-        };
-        if (P.mdup[piece] != 0 && min.nv <= SURTR_LITERAL_START_V)
-        {
-            // a sliver Mesh (a few vertices, a ring lists a neighbour twice): literal clipper from the start (see pair_global) --
-            // on the regular kernel's scratch (the half-size kernel's has no room for it: its retry list).  A larger Mesh with
-            // such a ring keeps the parallel clipper (one lane would take milliseconds for it) and falls back only on an error.
-            if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }
-            else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
-            continue;
-        }
-        int err;
-        if (HALF)
-        {
-            // no global fallback here: a pair that outgrows the half-size topology after all goes to the retry class
-            // (class 0), which a second launch of k_clip_pairs picks up
-            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, 0u, min, F, S, sh, L, consume);
-            else err = clip_any<false>(min, F, S, sh, L, consume);
-            __syncthreads();
-            if (err == SURTR_OVERFLOW)
-            {
-                if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p;
-                continue;
-            }
-        }
-        else
-        {
-            err = SURTR_OVERFLOW;
-            if (rec.img_fmt == IMG_NARROW) err = clip_image<false>(IA.base + (size_t)rec.img_off * 16u, rec.img_n, rec.img_h, rec.img_pc, min, F, S, sh, L, consume);
-            else if (rec.img_fmt != IMG_WIDE) err = clip_any<false>(min, F, S, sh, L, consume);
-            __syncthreads();
-            if (err == SURTR_OVERFLOW)
-            {
-                pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 0u);
-                continue;
-            }
-        }
-        if (err == SURTR_E_TOPOLOGY && min.nv <= SURTR_LITERAL_MESH_V)
-        {
-            __syncthreads();
-            if (HALF) { if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p; }       // (the regular kernel redoes the pair: see above)
-            else pair_global(P, piece, F, pool, wg, A, &sh, pairs, p, 1u);
-            continue;
-        }
-        if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
-        if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
-        if (tid == 0) pairs[p] = rec;
+        clip_pair_general<HALF>(sh, L, S, pool, wg, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
 #ifdef SURTR_STAMP
-        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[(cls_hi == 15 ? 51 : 21) + bkt], 1ull);
-            if (d > (1ull << 21)) printf("slow pair %u: %llu cycles, n %u F %u | cls %llu patch %llu fin/serial %llu tail %llu scan %llu sweep %llu create %llu jump %llu walk0 %llu pred %llu walk1 %llu\n", p, d, rec.img_n, F,
-                sh.ph[4], sh.ph[5], sh.ph[6], sh.ph[7], sh.ph[8], sh.ph[9], sh.ph[10], sh.ph[11], sh.ph[12], sh.ph[13], sh.ph[14]); }
+        if (tid == 0) { const unsigned long long d = __builtin_readcyclecounter() - pair_t0; int bkt = 0; while ((d >> bkt) > 1 && bkt < 30) ++bkt; bkt = bkt < 16 ? 0 : bkt - 16; if (bkt > 9) bkt = 9; atomicAdd(&g_stamp[(cls_hi == 15 ? 51 : 21) + bkt], 1ull); }
 #endif
     }
 #ifdef SURTR_STAMP
@@ -1115,11 +1129,13 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
 }
 
 // -------------------------------------------------------------- k_clip_pairs_wave
-// The same pairs through the record clipper (wave_clip.h): regular planes only, one LDS access per step of a plane's dependent
-// chain.  It takes the tickets of cost classes cls_hi..cls_lo like k_clip_pairs; a pair it cannot take (no narrow image, a
-// sliver piece, a cell of more than 64 planes) or has to give up (a plane with an in-plane vertex, an irregular cap, a ring of
-// more than seven entries, out of room: WC_BAIL) goes -- untouched, nothing of it published -- to the retry list (class 0
-// of the half table), which a launch of k_clip_pairs behind this kernel takes.
+// The same pairs through the record clipper (wave_clip.h): regular planes only, one memory access per step of a plane's
+// dependent chain, the band streamed from HBM bucket by bucket.  It takes the tickets of cost classes cls_hi..cls_lo like
+// k_clip_pairs.  A pair it cannot take (no narrow image, a sliver piece, a cell of more than 64 planes, an original that lies in
+// a plane) or has to give up (a cut point in a later plane, an irregular cap, a ring of more than seven entries, out of room:
+// WC_BAIL -- nothing of the pair has been published, its image is untouched) is clipped right here by the general clipper, on
+// the same LDS bytes: k_prep_pairs puts the pairs it knows to be irregular into the heaviest class, so they come first.
+struct GenLds { Shared sh; LdsTopo L; };
 __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_wave(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
@@ -1127,10 +1143,15 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                                                          const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
 {
-    __shared__ WcLds W;
+    constexpr size_t kBytes = sizeof(WcLds) > sizeof(GenLds) ? sizeof(WcLds) : sizeof(GenLds);
+    __shared__ alignas(16) unsigned char lds_raw[kBytes];
+    WcLds& W = *reinterpret_cast<WcLds*>(lds_raw);
+    GenLds& Gn = *reinterpret_cast<GenLds*>(lds_raw);
     const uint32_t tid = threadIdx.x;
-    // this workgroup's scratch slot, used raw: sorted records + positions of a band's originals, positions of the cut points
+    // this workgroup's scratch slot: used raw by the record clipper (sorted records + positions of a band's originals, positions
+    // of the cut points), carved as a Scratch by the general clipper
     char* slot = pool.base + (size_t)blockIdx.x * pool.per_wg;
+    Scratch S = carve(pool, blockIdx.x);
     while (true)
     {
         __syncthreads();
@@ -1194,7 +1215,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
         if (tid == 0) atomicAdd(&A.cursors[err == WC_BAIL ? 89 : 88], 1u);       // (diagnostic: pairs the record clipper took / handed on)
         if (err == WC_BAIL)
         {
-            if (tid == 0) horder[atomicAdd(&A.cursors[64], 1u)] = p;
+            __syncthreads();
+            clip_pair_general(Gn.sh, Gn.L, S, pool, blockIdx.x, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
             continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
@@ -2970,8 +2992,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
     // (it reuses the scratch slots of the first launch)
     PROF_BEGIN_ON(10, st2);
-    if (n_pairs && (ctx->half_on || wave_on))
-        hipLaunchKernelGGL(k_clip_pairs, dim3(wave_on ? n_wg : std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+    if (n_pairs && ctx->half_on)
+        hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
     PROF_END_ON(10, st2);
     HIPCHK(hipEventRecord(ctx->ev_big, st2));
