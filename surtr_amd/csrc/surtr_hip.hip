@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                                                          uint32_t n_pairs,
                                                          ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
                                                          const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
-                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur)
+                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0)
 {
     constexpr size_t kBytes = sizeof(WcLds) > sizeof(GenLds) ? sizeof(WcLds) : sizeof(GenLds);
     __shared__ alignas(16) unsigned char lds_raw[kBytes];
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
             bool fits = false;
             const WcGlob g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WcLds::kNR, fits);
             if (fits) err = wc_load(W, im, F, g, zmask, ctr, A.cursors + 96);
-            if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WcLds::kNR, o, ctr, A.cursors + 96);
+            if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WcLds::kNR, o, ctr, A.cursors + 96, walk0);
             if (err == 0 && o.nLive != 0u) err = wc_park(W, F, rec.img_n, o, g, A, rec, ctr, A.cursors + 96);
 #ifdef SURTR_STAMP
             __syncthreads();
@@ -2970,12 +2970,17 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
     PROF_END(8);
     // the regular pairs on one wave each (wave_clip.h); what it hands on comes back through the retry launch below
-    bool wave_on = true;
+    // (measured on blocks of configs[3]: the record clipper wins once the pairs queue up -- 4 096 pairs 1.88 -> 1.65 ms, 2 048 pairs
+    // 2.35 -> 2.30 ms for the event -- and loses when every pair has a workgroup to itself: 1 024 pairs 1.63 -> 1.69 ms, 512 pairs
+    // 1.33 -> 1.45 ms; its loader sorts the band, which the general clipper's image copy does not have to)
+    bool wave_on = n_pairs > 3u * max_wg;
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
+    uint32_t walk0 = SURTR_WWALK0;
+    if (const char* e = getenv("SURTR_WWALK0")) { const int v = atoi(e); if (v >= 0 && v <= 64) walk0 = (uint32_t)v; }
     PROF_BEGIN_ON(11, st2);
     if (n_pairs && wave_on)
         hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u, walk0);
     PROF_END_ON(11, st2);
     PROF_BEGIN_ON(0, st2);
     if (n_pairs && !wave_on)

@@ -216,6 +216,72 @@ __device__ __forceinline__ uint2 wc_scan(LT& W, uint32_t& sc, uint32_t N, C1 cou
     return make_uint2(SURTR_UNIFORM(tot.x), SURTR_UNIFORM(tot.y));
 }
 
+// The same scan in two halves, so that the caller can act on the totals (carve lists, check room) before anything is placed,
+// and with the counts of the first NC blocks of every wave kept in registers between the sweeps (what count() read need not be
+// read again): count(i, aux&) -> (a, b); mid() runs between the first sweep and the barrier; place(i, exclusive a, exclusive b,
+// (a, b), aux).
+template <int NC> struct WcScanState { uint32_t b0, b1; uint2 run; uint2 cc[NC]; uint32_t ax[NC]; };
+template <int NC, class LT, class C, class M>
+__device__ __forceinline__ uint2 wc_scan_count(LT& W, uint32_t& sc, uint32_t N, WcScanState<NC>& st, C count, M mid)
+{
+    const uint32_t lane = lane_id(), w = wave_id(), nw = group_waves();
+    const uint32_t nb = (N + SURTR_LANES - 1u) >> SURTR_LSH, nbw = (nb + nw - 1u) / nw;
+    st.b0 = w * nbw; st.b1 = st.b0 + nbw < nb ? st.b0 + nbw : nb;
+    uint32_t* ws = W.wsum[sc & 1u];
+    ++sc;
+    uint2 mine = make_uint2(0u, 0u);
+#pragma unroll
+    for (int bi = 0; bi < NC; ++bi)
+    {
+        st.cc[bi] = make_uint2(0u, 0u); st.ax[bi] = 0u;
+        const uint32_t i = ((st.b0 + (uint32_t)bi) << SURTR_LSH) + lane;
+        if (st.b0 + (uint32_t)bi < st.b1 && i < N) { st.cc[bi] = count(i, st.ax[bi]); mine.x += st.cc[bi].x; mine.y += st.cc[bi].y; }
+    }
+    for (uint32_t b = st.b0 + (uint32_t)NC; b < st.b1; ++b)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        if (i < N) { uint32_t a; const uint2 c = count(i, a); mine.x += c.x; mine.y += c.y; }
+    }
+    const uint2 inc = wave_incl_scan2(mine);
+    if (lane == SURTR_LANES - 1u) { ws[2u * w] = inc.x; ws[2u * w + 1u] = inc.y; }
+    mid();
+    __syncthreads();
+    uint2 run = make_uint2(0u, 0u), tot = make_uint2(0u, 0u);
+    for (uint32_t q = 0; q < nw; ++q)
+    {
+        const uint32_t a = ws[2u * q], b = ws[2u * q + 1u];
+        if (q < w) { run.x += a; run.y += b; }
+        tot.x += a; tot.y += b;
+    }
+    st.run = run;
+    return make_uint2(SURTR_UNIFORM(tot.x), SURTR_UNIFORM(tot.y));
+}
+template <int NC, class C, class P>
+__device__ __forceinline__ void wc_scan_place(uint32_t N, WcScanState<NC>& st, C count, P place)
+{
+    const uint32_t lane = lane_id();
+    uint2 run = st.run;
+#pragma unroll
+    for (int bi = 0; bi < NC; ++bi)
+    {
+        if (st.b0 + (uint32_t)bi >= st.b1) break;
+        const uint32_t i = ((st.b0 + (uint32_t)bi) << SURTR_LSH) + lane;
+        const uint2 c = st.cc[bi];
+        const uint2 s = wave_incl_scan2(c);
+        if (i < N) place(i, run.x + s.x - c.x, run.y + s.y - c.y, c, st.ax[bi]);
+        run.x += lane_bcast(s.x, SURTR_LANES - 1u); run.y += lane_bcast(s.y, SURTR_LANES - 1u);
+    }
+    for (uint32_t b = st.b0 + (uint32_t)NC; b < st.b1; ++b)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        uint2 c = make_uint2(0u, 0u); uint32_t a = 0u;
+        if (i < N) c = count(i, a);
+        const uint2 s = wave_incl_scan2(c);
+        if (i < N) place(i, run.x + s.x - c.x, run.y + s.y - c.y, c, a);
+        run.x += lane_bcast(s.x, SURTR_LANES - 1u); run.y += lane_bcast(s.y, SURTR_LANES - 1u);
+    }
+}
+
 __device__ __forceinline__ uint32_t wc_popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
 
 // Sorts the band: stable counting sort by first clipping plane; records and positions of the originals go to the workgroup's
@@ -329,7 +395,7 @@ __device__ __attribute__((always_inline)) inline int wc_load(LT& W, const WcImg 
 // The plane loop.  Returns 0 (out.nLive == 0: nothing is left) or WC_BAIL.
 template <class LT>
 __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint32_t F, const uint32_t n, const uint32_t dropTotal, unsigned long long zmask,
-                                                               const WcGlob g, const uint32_t capPool, WcOut& out, WcCtr& ctr, uint32_t* __restrict__ why)
+                                                               const WcGlob g, const uint32_t capPool, WcOut& out, WcCtr& ctr, uint32_t* __restrict__ why, const uint32_t walk0 = SURTR_WWALK0)
 {
     const uint32_t tid = threadIdx.x, G = group_size();
     unsigned char* B = W.U;
@@ -348,13 +414,13 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         uint32_t ltop = 8u * LT::kNR;                     // stage and lists are carved downwards from the top (16-bit word index, 16-byte steps)
         auto carve = [&](uint32_t cnt16) -> uint32_t { ltop -= (cnt16 + 7u) & ~7u; return ltop; };
         if (4u * rtop + 8u * nCo + nl + 64u > ltop) WC_RET(4);
-        // ---- stage: this plane's originals into LDS (their records are final: every patch of an earlier plane is in) ----
+        // ---- stage: this plane's originals into LDS (their records are final: every patch of an earlier plane is in).  The
+        //      first two records of every thread are in flight while the cut points are filtered. ----
         const uint32_t stage = carve(8u * nCo) / 8u;      // first unit of the stage
-        for (uint32_t i = tid; i < nCo; i += G)
-        {
-            const WcW4 wr = g.grec[b0 + i];
-            __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16);
-        }
+        auto stage_put = [&](uint32_t i, const WcW4& wr) { __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16); };
+        WcW4 sg0 = WcW4{0u, 0u, 0u, 0u}, sg1 = WcW4{0u, 0u, 0u, 0u};
+        if (tid < nCo) sg0 = g.grec[b0 + tid];
+        if (tid + G < nCo) sg1 = g.grec[b0 + tid + G];
         // where the record of a vertex that is in LDS sits: a cut point (pool, 8-byte units from the bottom) or an original of this
         // plane (stage); t16_of: 16-bit word index of its tail
         auto off_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 8u * (e - WC_MAXN) : 16u * (stage + (e - b0)); };
@@ -363,12 +429,15 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         // ---- the clipped cut points (first clipping plane == k), in creation order; the others move to the other nlist, in order ----
         const uint32_t cnew = carve(nl);
         const uint16_t* nin = W.nlist[cur]; uint16_t* nout = W.nlist[cur ^ 1u];
-        auto nfl = [&](uint32_t i) -> uint2 { const bool c = (wc_ld16(B, 4u * ((uint32_t)nin[i] - WC_MAXN) + 3u) & 0xFFu) == k; return make_uint2(c ? 1u : 0u, c ? 0u : 1u); };
-        const uint2 nt = wc_scan(W, sc, nl, nfl, nfl, [&](uint32_t i, uint32_t xc, uint32_t xk) {
-            const uint32_t e = nin[i];
-            if ((wc_ld16(B, 4u * (e - WC_MAXN) + 3u) & 0xFFu) == k) wc_st16(B, cnew + xc, e); else nout[xk] = (uint16_t)e;
+        WcScanState<2> st1;
+        auto nfl = [&](uint32_t i, uint32_t& e) -> uint2 { e = nin[i]; const bool c = (wc_ld16(B, 4u * (e - WC_MAXN) + 3u) & 0xFFu) == k; return make_uint2(c ? 1u : 0u, c ? 0u : 1u); };
+        const uint2 nt = wc_scan_count<2>(W, sc, nl, st1, nfl, [&]() {
+            if (tid < nCo) stage_put(tid, sg0);
+            if (tid + G < nCo) stage_put(tid + G, sg1);
+            for (uint32_t i = tid + 2u * G; i < nCo; i += G) stage_put(i, g.grec[b0 + i]);
         });
         const uint32_t nCn = nt.x, keepn = nt.y;
+        wc_scan_place<2>(nl, st1, nfl, [&](uint32_t, uint32_t xc, uint32_t xk, uint2 c, uint32_t e) { if (c.x) wc_st16(B, cnew + xc, e); else nout[xk] = (uint16_t)e; });
         cur ^= 1u;
         __syncthreads();
         WSTAMP(2);
@@ -392,72 +461,74 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         const uint32_t cbase = carve(nC), ckm8 = 2u * carve((nC + 1u) / 2u);      // ckm8: byte index
         auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : wc_ld16(B, cnew + (i - nCo)); };
         bool bad = false;
-        const uint2 mt = wc_scan(W, sc, nC,
-            [&](uint32_t i) -> uint2 {
-                const WcRec r = rec_of(clipped_id(i));
-                // the first clipping plane of every cut point among the neighbours: all seven loads in flight together
-                uint32_t ee[7], tl[7];
+        WcScanState<2> st2;
+        auto kfn = [&](uint32_t i, uint32_t& aux) -> uint2 {
+            const uint32_t id = clipped_id(i);
+            const WcRec r = rec_of(id);
+            // the first clipping plane of every cut point among the neighbours: all seven loads in flight together
+            uint32_t ee[7], tl[7];
 #pragma unroll
-                for (uint32_t q = 0; q < 7u; ++q) ee[q] = r.e(q);
+            for (uint32_t q = 0; q < 7u; ++q) ee[q] = r.e(q);
 #pragma unroll
-                for (uint32_t q = 0; q < 7u; ++q) tl[q] = wc_ld16(B, (ee[q] >= WC_MAXN && ee[q] < WC_SENT) ? 4u * (ee[q] - WC_MAXN) + 3u : 3u);
-                uint32_t km = 0;
+            for (uint32_t q = 0; q < 7u; ++q) tl[q] = wc_ld16(B, (ee[q] >= WC_MAXN && ee[q] < WC_SENT) ? 4u * (ee[q] - WC_MAXN) + 3u : 3u);
+            uint32_t km = 0;
 #pragma unroll
-                for (uint32_t q = 0; q < 7u; ++q)
-                {
-                    // an original is kept when it sits in a later bucket, a cut point when its own first clipping plane is later;
-                    // a dropped vertex (WC_SENT) goes with this plane
-                    const bool kept = ee[q] < WC_MAXN ? ee[q] >= b1 : (ee[q] < WC_SENT && (tl[q] & 0xFFu) > k);
-                    if (kept) km |= 1u << q;
-                }
-                // a ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354)
-                if (km & (km - 1u))
-                {
+            for (uint32_t q = 0; q < 7u; ++q)
+            {
+                // an original is kept when it sits in a later bucket, a cut point when its own first clipping plane is later;
+                // a dropped vertex (WC_SENT) goes with this plane
+                const bool kept = ee[q] < WC_MAXN ? ee[q] >= b1 : (ee[q] < WC_SENT && (tl[q] & 0xFFu) > k);
+                if (kept) km |= 1u << q;
+            }
+            // a ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354)
+            if (km & (km - 1u))
+            {
 #pragma unroll
-                    for (uint32_t q = 1; q < 7u; ++q)
+                for (uint32_t q = 1; q < 7u; ++q)
 #pragma unroll
-                        for (uint32_t q2 = 0; q2 < q; ++q2)
-                            if (((km >> q) & 1u) && ((km >> q2) & 1u) && ee[q] == ee[q2]) bad = true;
-                }
-                wc_st8(B, ckm8 + i, km);
-                return make_uint2((uint32_t)__builtin_popcount(km), 0u);
-            },
-            [&](uint32_t i) -> uint2 { return make_uint2((uint32_t)__builtin_popcount(wc_ld8(B, ckm8 + i)), 0u); },
-            [&](uint32_t i, uint32_t xm, uint32_t) { wc_st16(B, cbase + i, xm); });
-        const uint32_t M = mt.x;
-        if (wc_any(W, ac, bad)) WC_RET(8);
+                    for (uint32_t q2 = 0; q2 < q; ++q2)
+                        if (((km >> q) & 1u) && ((km >> q2) & 1u) && ee[q] == ee[q2]) bad = true;
+            }
+            wc_st8(B, ckm8 + i, km);
+            aux = km | (id << 8) | (((r.tail() >> 8) & 7u) << 24);
+            return make_uint2((uint32_t)__builtin_popcount(km), 0u);
+        };
+        const uint32_t M = wc_scan_count<2>(W, sc, nC, st2, kfn, [&]() {}).x;
         if (M > 4095u || keepn + M > SURTR_WNL || nfree + nCn > SURTR_WNL) WC_RET(9);
-        if (4u * rtop + 3u * M + 2u * nC + 64u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
-        const uint32_t src = carve(M), wst = carve(M), xid = carve(M), nd = carve(2u * nC);
-        // ---- record units of the new vertices: those of cut points that are gone first, then the end of the pool ----
+        const uint32_t bmw = (M + 31u) / 32u;
+        if (4u * rtop + 3u * M + 2u * bmw + 2u * nC + 64u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
+        const uint32_t src = carve(M), srcid = carve(M), wst = carve(M), nd = carve(2u * nC), bm = carve(2u * bmw);
+        // ---- record units of the new vertices: those of cut points that are gone first (from the end of the free list), then the
+        //      end of the pool ----
+        const uint32_t fromf = nfree < M ? nfree : M, fromt = M - fromf, fbase = nfree, tbase = rtop;
         {
-            const uint32_t fromf = nfree < M ? nfree : M, fromt = M - fromf;
             const uint32_t room = ltop / 4u > rtop ? ltop / 4u - rtop : 0u;
             if (fromt > room || rtop + fromt > capPool) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(16); }
-            for (uint32_t t = tid; t < M; t += G) wc_st16(B, xid + t, WC_MAXN + (t < fromf ? (uint32_t)W.freel[nfree - 1u - t] : rtop + (t - fromf)));
             nfree -= fromf; rtop += fromt;
         }
+        auto xof = [&](uint32_t t) -> uint32_t { return WC_MAXN + (t < fromf ? (uint32_t)W.freel[fbase - 1u - t] : tbase + (t - fromf)); };
+        for (uint32_t q = tid; q < bmw; q += G) wc_st32(B, bm + 2u * q, 0u);
         WSTAMP(3);
         WCOUNT(18, 1); WCOUNT(19, nC); WCOUNT(20, M); WCOUNT(21, nl);
 #ifdef SURTR_STAMP
-        if (tid == 0u) { const unsigned long long need = 2ull * (4u * rtop + (8u * LT::kNR - ltop)); if (need > W.ph[31]) W.ph[31] = need; if (k < 2u) { if (need > W.ph[30]) W.ph[30] = need; } else if (need > W.ph[29]) W.ph[29] = need; }
+        if (tid == 0u) { const unsigned long long need = 2ull * (4u * rtop + (8u * LT::kNR - ltop)); if (need > W.ph[31]) W.ph[31] = need; if (k >= 2u && need > W.ph[29]) W.ph[29] = need; }
 #endif
         // ---- every clipped vertex gets its position in the list into its tail; source (clipped vertex, slot) of every new
         //      vertex, in the reference's order (:333-357) ----
-        for (uint32_t i = tid; i < nC; i += G)
-        {
-            const uint32_t km = wc_ld8(B, ckm8 + i);
-            uint32_t t = wc_ld16(B, cbase + i);
-            const uint32_t t16 = t16_of(clipped_id(i));
-            const uint32_t tl = wc_ld16(B, t16);
-            wc_st16(B, t16, 0x8000u | (((tl >> 8) & 7u) << 12) | i);
-            for (uint32_t m = km; m; m &= m - 1u, ++t) wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12));
-        }
+        // (blocks beyond those held in registers: the mask is read back, not derived again -- tails are being rewritten by now)
+        auto kfn2 = [&](uint32_t i, uint32_t& aux) -> uint2 {
+            const uint32_t id = clipped_id(i), km = wc_ld8(B, ckm8 + i);
+            aux = km | (id << 8) | (((wc_ld16(B, t16_of(id)) >> 8) & 7u) << 24);
+            return make_uint2((uint32_t)__builtin_popcount(km), 0u);
+        };
+        wc_scan_place<2>(nC, st2, kfn2, [&](uint32_t i, uint32_t xm, uint32_t, uint2, uint32_t aux) {
+            const uint32_t km = aux & 0xFFu, id = (aux >> 8) & 0xFFFFu, len = aux >> 24;
+            wc_st16(B, cbase + i, xm);
+            wc_st16(B, t16_of(id), 0x8000u | (len << 12) | i);
+            uint32_t t = xm;
+            for (uint32_t m = km; m; m &= m - 1u, ++t) { wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12)); wc_st16(B, srcid + t, id); }
+        });
         __syncthreads();
-        for (uint32_t t = tid; t < M; t += G) wc_st16(B, 4u * (wc_ld16(B, xid + t) - WC_MAXN), WC_NONE);      // predecessor: not yet known
-        // the cut points this plane clips are gone after it: their units go to the free list (nobody takes from it before the next plane)
-        for (uint32_t i = tid; i < nCn; i += G) W.freel[nfree + i] = (uint16_t)(wc_ld16(B, cnew + i) - WC_MAXN);
-        nfree += nCn;
         WSTAMP(4);
         // ---- successor of every new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j,
         //      and so on through clipped vertices, until the entry is a kept vertex -- the new vertex on that edge (:367-425) ----
@@ -491,17 +562,25 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                 p = q ? q - 1u : le - 1u; cv = e; pcv = te & 0xFFFu; rc = re;
             }
         };
+        // every new vertex must be the successor of exactly one other: all M walks end on one of the M new vertices, so it is
+        // enough that no two end on the same one (a bit per new vertex).  (A cap of two vertices gives rings [Z, Z, kept], as in
+        // the reference; a later plane that meets such a ring at a clipped vertex finds it in the doubled-neighbour test above.)
+        auto arrive = [&](uint32_t t, uint32_t end) {
+            wc_st16(B, wst + t, 0x8000u | end);
+            uint32_t* word = (uint32_t*)(void*)(B + 2u * (size_t)(bm + 2u * (end >> 5)));
+            if (end == t || (atomicOr(word, 1u << (end & 31u)) & (1u << (end & 31u)))) { SURTR_DBG("  wc walk: ends on itself / second arrival t=%u end=%u k=%u\n", t, end, k); fail = true; }
+        };
         bool paused = false;
         for (uint32_t t = tid; t < M; t += G)
         {
             const uint32_t s = wc_ld16(B, src + t);
-            uint32_t pcv = s & 0xFFFu, cv = clipped_id(pcv);
+            uint32_t pcv = s & 0xFFFu, cv = wc_ld16(B, srcid + t);
             const uint32_t j = s >> 12;
             WcRec rc = rec_of(cv);
             const uint32_t lv = (rc.tail() >> 12) & 7u;
             uint32_t p = j ? j - 1u : lv - 1u, steps = 0;
-            const uint32_t end = walk(cv, pcv, p, rc, steps, SURTR_WWALK0, false);
-            if (end != WC_NONE) wc_st16(B, wst + t, 0x8000u | end);
+            const uint32_t end = walk(cv, pcv, p, rc, steps, walk0, false);
+            if (end != WC_NONE) arrive(t, end);
             else { wc_st16(B, wst + t, pcv | (p << 12)); paused = true; }
         }
         const bool anyPaused = wc_any(W, ac, paused, 0u);
@@ -532,10 +611,14 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                 bool ch = false;
                 for (uint32_t i = tid; i < nC; i += G)
                 {
+                    // (two levels per round: whatever value a lane reads is a vertex further down the same run, with its distance)
                     const uint32_t a = wc_ld32(B, nd + 2u * i), j1 = a & 0xFFFFu;
                     if (j1 == i) continue;
                     const uint32_t b2 = wc_ld32(B, nd + 2u * j1), j2 = b2 & 0xFFFFu;
-                    if (j2 != j1) { wc_st32(B, nd + 2u * i, j2 | (((a >> 16) + (b2 >> 16)) << 16)); ch = true; }
+                    if (j2 == j1) continue;
+                    const uint32_t b3 = wc_ld32(B, nd + 2u * j2), j3 = b3 & 0xFFFFu;
+                    wc_st32(B, nd + 2u * i, j3 | (((a >> 16) + (b2 >> 16) + (j3 != j2 ? (b3 >> 16) : 0u)) << 16));
+                    ch = true;
                 }
                 if (!wc_any(W, ac, ch, 0u)) break;
             }
@@ -544,10 +627,10 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             {
                 const uint32_t ws = wc_ld16(B, wst + t);
                 if (ws & 0x8000u) continue;
-                uint32_t pcv = ws & 0xFFFu, cv = clipped_id(pcv), p = ws >> 12, steps = SURTR_WWALK0;
+                uint32_t pcv = ws & 0xFFFu, cv = clipped_id(pcv), p = ws >> 12, steps = walk0;
                 WcRec rc = rec_of(cv);
                 const uint32_t end = walk(cv, pcv, p, rc, steps, 0xFFFFFFFFu, true);
-                if (end != WC_NONE) wc_st16(B, wst + t, 0x8000u | end);
+                if (end != WC_NONE) arrive(t, end);
                 else fail = true;
 #ifdef SURTR_STAMP
                 atomicAdd(&g_wstamp[22], (unsigned long long)steps); atomicMax(&g_wstamp[23], (unsigned long long)steps);      // (rare: resumed walks only)
@@ -555,16 +638,17 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             }
             WSTAMP(7);
         }
-        if (wc_any(W, ac, fail, 1u)) WC_RET(11);
-        WSTAMP(25);
-        // ---- the new vertices: position, first clipping plane, record [pred, succ, kept end], back-link of the kept end ----
+        // ---- the new vertices: position, first clipping plane, record [pred, succ, kept end], back-link of the kept end.
+        //      (Nothing here reads what another thread's walk left: no barrier between the walks and this.) ----
         uint32_t myz0 = 0, myz1 = 0;
         uint16_t* nnow = W.nlist[cur];
         for (uint32_t t = tid; t < M; t += G)
         {
-            const uint32_t s = wc_ld16(B, src + t), end = wc_ld16(B, wst + t) & 0xFFFu;
-            const uint32_t v = clipped_id(s & 0xFFFu), j = s >> 12;
-            const uint32_t X = wc_ld16(B, xid + t), Z = wc_ld16(B, xid + end);
+            const uint32_t ws = wc_ld16(B, wst + t);
+            if (!(ws & 0x8000u)) continue;            // (a walk that failed: the pair is given up below)
+            const uint32_t end = ws & 0xFFFu;
+            const uint32_t v = wc_ld16(B, srcid + t), j = wc_ld16(B, src + t) >> 12;
+            const uint32_t X = xof(t), Z = xof(end);
             const WcRec r = rec_of(v);
             const uint32_t u = r.e(j);
             const float4 pa = v < WC_MAXN ? g.gpos[v] : g.cpos[v - WC_MAXN];
@@ -572,7 +656,6 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             // the kept end: an original lives in global memory, a cut point in LDS
             WcRec ru;
             if (u < WC_MAXN) { const WcW4 wr = g.grec[u]; ru = WcRec{wr.a, wr.b, wr.c, wr.d}; } else ru = wc_rec(B, 8u * (u - WC_MAXN), true);
-            if (end == t) { SURTR_DBG("  wc walk: ends on itself k=%u\n", k); fail = true; continue; }
             const uint32_t ux = X - WC_MAXN, uz = Z - WC_MAXN;
             wc_st16(B, 4u * uz, X);                                                // X is the predecessor of Z
             // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
@@ -599,17 +682,13 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         }
         if (myz0) atomicOr(&W.zm[0], myz0);
         if (myz1) atomicOr(&W.zm[1], myz1);
-        __syncthreads();
+        if (wc_any(W, ac, fail || bad, 1u)) WC_RET(11);
         WSTAMP(8);
-        // every new vertex must be the successor of exactly one other (a cap of two vertices gives rings [Z, Z, kept], as in the
-        // reference; a later plane that meets such a ring at a clipped vertex finds it in the doubled-neighbour test above)
-        for (uint32_t t = tid; t < M && !fail; t += G)
-        {
-            const uint32_t X = wc_ld16(B, xid + t), Z = wc_ld16(B, xid + (wc_ld16(B, wst + t) & 0xFFFu));
-            if (wc_ld16(B, 4u * (X - WC_MAXN)) == WC_NONE || Z == X || wc_ld16(B, 4u * (Z - WC_MAXN)) != X) { SURTR_DBG("  wc check: X=%u succ=%u k=%u M=%u\n", X, Z, k, M); fail = true; }
-        }
-        if (wc_any(W, ac, fail, 1u)) WC_RET(11);
         zmask |= (unsigned long long)SURTR_UNIFORM(W.zm[0]) | ((unsigned long long)SURTR_UNIFORM(W.zm[1]) << 32);
+        // the cut points this plane clipped are gone: their units go to the free list (nobody takes from it before the next
+        // plane's kept masks are through a barrier)
+        for (uint32_t i = tid; i < nCn; i += G) W.freel[nfree + i] = (uint16_t)(wc_ld16(B, cnew + i) - WC_MAXN);
+        nfree += nCn;
         nLive = nLive - nC + M; nl = keepn + M;
         WSTAMP(9);
         if (nLive + dropAlive < 4u) { nLive = 0; break; }                          // (:497-499)
