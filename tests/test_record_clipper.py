@@ -1,0 +1,116 @@
+"""The record clipper (surtr_amd/csrc/wave_clip.h, kernel k_clip_pairs_wave): the regular planes of the Mesh clip on 16-byte
+records with the band streamed bucket by bucket.  It must give the general clipper's -- i.e. the oracle's -- event bit for
+bit, whichever pairs it takes and whichever it hands to the general clipper in place (Src/Poly.cpp:265-500 either way).
+CPU tier: the single-lane emulation with three capacity settings (pairs that fit, pairs that run out of room mid-way,
+pointer jumping from the first / second walk step); GPU tier: BASELINE configs[3] with the clipper forced on and off."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import assert_event_equal
+from surtr_amd import meshgen, scenes
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOPO = ("frag_ids", "mesh_vert_off", "mesh_nbr_off", "mesh_nbr", "conv_vert_off", "conv_nbr_off", "conv_nbr", "idx_off", "idx")
+
+
+def _event(engine_mod, oracle, sc, cells, flags=3, threads=8):
+    eng = engine_mod.Engine(0)
+    try:
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        eng.upload_pattern(sc["face_off"], sc["v012"])
+        eng.place_cells(sc["scale"], sc["translate"])
+        c = eng.fracture_event(0, cells, flags=flags)
+        qs = eng.queue_stats()
+        got = eng.download()
+    finally:
+        eng.close()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=bool(flags & 1), render=bool(flags & 2),
+                       threads=threads, cell_end=cells)
+    return c, got, ref, qs
+
+
+@pytest.mark.parametrize("lib", ["libsurtr_emul.so", "libsurtr_emul_mid.so", "libsurtr_emul_small.so"])
+def test_record_clipper_emulation_torus(emul_lib_path, oracle, monkeypatch, lib):
+    from surtr_amd import engine
+    monkeypatch.setenv("SURTR_WAVE", "1")
+    engine._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), lib))
+    try:
+        sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+        c, got, ref, qs = _event(engine, oracle, sc, 256 if lib == "libsurtr_emul.so" else 96)
+    finally:
+        engine._use_library_for_tests(None)
+    assert c.status == 0 and c.n_frag == ref["frag_ids"].shape[0] > 80
+    assert_event_equal(got, ref)
+    assert np.array_equal(got["mesh_pos"], ref["mesh_pos"])       # same float program => bit-exact
+    took, handed = int(qs[88]), int(qs[89])
+    assert took + handed > 0
+    if lib == "libsurtr_emul.so":
+        assert took > 200, "the record clipper took %d pairs" % took       # (its capacities hold every band of this scene)
+        assert handed > 0, "no pair with an in-plane vertex was handed to the general clipper"
+    else:
+        assert took > 0 and handed > took          # (tiny capacities: most pairs run out of room and are redone in place)
+
+
+def test_record_clipper_emulation_islands_and_empty_results(emul_engine, oracle, monkeypatch):
+    """Two disjoint cubes in one piece (islands), and cells that keep nothing of the Mesh."""
+    monkeypatch.setenv("SURTR_WAVE", "1")
+    v, t = meshgen.bumpy_torus(60, 40)
+    v2 = np.concatenate([v, v * np.float32(0.25) + np.float32([4, 0, 0])])
+    t2 = np.concatenate([t, t + len(v)])
+    sc = scenes.make_scene(v2, t2, 48)
+    c, got, ref, qs = _event(emul_engine, oracle, sc, 48)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    assert int(qs[88]) > 0
+
+
+def test_record_clipper_off_is_the_general_clipper(emul_engine, oracle, monkeypatch):
+    monkeypatch.setenv("SURTR_WAVE", "0")
+    sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+    c, got, ref, qs = _event(emul_engine, oracle, sc, 64)
+    assert_event_equal(got, ref)
+    assert int(qs[88]) == 0 and int(qs[89]) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_record_clipper_torus_4096_digest(gpu_engine, monkeypatch, wave):
+    """BASELINE configs[3] with the record clipper forced on / off: the committed digests either way."""
+    monkeypatch.setenv("SURTR_WAVE", wave)
+    want = json.load(open(os.path.join(HERE, "digests.json")))["torus4096"]
+    sc = scenes.torus_scene(4096)
+    eng = gpu_engine.Engine(0)
+    try:
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+        c = eng.fracture_event(0, 4096, flags=3)
+        qs = eng.queue_stats()
+        got = eng.download()
+    finally:
+        eng.close()
+    assert c.status == 0 and c.n_frag == want["n_frag"] and c.mesh_verts == want["mesh_verts"] and c.n_idx == want["n_idx"]
+    for k in TOPO:
+        assert hashlib.sha256(np.ascontiguousarray(got[k]).tobytes()).hexdigest() == want[k], k
+    if wave == "1":
+        assert int(qs[88]) > 2500, "the record clipper took only %d pairs" % int(qs[88])
+        assert 0 < int(qs[89]) < 400
+    else:
+        assert int(qs[88]) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells,walk0", [(512, "0"), (512, "1"), (1024, "9")])
+def test_record_clipper_small_blocks_and_walk_thresholds(gpu_engine, oracle, monkeypatch, cells, walk0):
+    """Blocks of configs[3] that the engine would leave to the general clipper, forced through the record clipper, with the
+    pointer jumping starting at the first / second / tenth walk step."""
+    monkeypatch.setenv("SURTR_WAVE", "1")
+    monkeypatch.setenv("SURTR_WWALK0", walk0)
+    sc = scenes.torus_scene(4096)
+    c, got, ref, qs = _event(gpu_engine, oracle, sc, cells, threads=16)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    assert int(qs[88]) > 0
