@@ -91,6 +91,9 @@ const char* surtr_strerror(int code);
 const char* surtr_last_error(surtr_ctx* ctx);
 /* Use this HIP stream (hipStream_t passed as void*) for all work; NULL = default stream. */
 int surtr_set_stream(surtr_ctx* ctx, void* hip_stream);
+/* The stream the context's kernels (surtr_event_pack_dev included) are launched on: a caller that consumes a device blob on
+ * another stream orders the two with an event recorded here. */
+int surtr_get_stream(surtr_ctx* ctx, void** hip_stream);
 /* Override the per-workgroup scratch capacities (vertices, neighbour entries); 0 = automatic. */
 int surtr_set_scratch(surtr_ctx* ctx, uint32_t max_verts, uint32_t max_nbrs);
 /* Override the result arena capacities (vertices, neighbour entries, indices); 0 = automatic. */

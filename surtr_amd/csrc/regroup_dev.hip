@@ -339,7 +339,11 @@ extern "C" int surtr_event_regroup(surtr_ctx* ctx, int partial, uint32_t n_spher
         if (head[0]) return (int)head[0];
         if (head[1] > cap_edges) return SURTR_E_CAPACITY;
         const uint32_t ne = head[1];
-        for (int round = 0; round < 64 && ne; ++round)
+        // min-label propagation with one pointer jump per round converges in a number of rounds bounded by the number of
+        // pieces (labels only decrease); it runs until a round changes nothing -- a chain numbered against the grain takes as
+        // many rounds as it is long, not 64
+        bool converged = ne == 0;
+        for (uint32_t round = 0; round < n + 8u && ne; ++round)
         {
             HIPCHK(hipMemsetAsync(d_err + 2, 0, 4, st));
             const uint32_t work = std::max(ne, n);
@@ -347,8 +351,9 @@ extern "C" int surtr_event_regroup(surtr_ctx* ctx, int partial, uint32_t n_spher
             uint32_t changed = 0;
             HIPCHK(hipMemcpyAsync(&changed, d_err + 2, 4, hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            if (!changed) break;
+            if (!changed) { converged = true; break; }
         }
+        if (!converged) return SURTR_E_STATE;      // (cannot happen: see the bound above; never hand out unconverged labels)
         HIPCHK(hipMemcpyAsync(lab.data(), d_lab.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }

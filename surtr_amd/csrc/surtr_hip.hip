@@ -2589,6 +2589,13 @@ int surtr_set_stream(surtr_ctx* ctx, void* s)
     return SURTR_OK;
 }
 
+int surtr_get_stream(surtr_ctx* ctx, void** s)
+{
+    if (!ctx || !s) return SURTR_E_INVALID;
+    *s = (void*)ctx->stream;
+    return SURTR_OK;
+}
+
 int surtr_set_scratch(surtr_ctx* ctx, uint32_t mv, uint32_t mh)
 {
     if (!ctx) return SURTR_E_INVALID;

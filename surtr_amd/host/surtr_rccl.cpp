@@ -19,10 +19,12 @@ struct DevBuf
 
 GatheredFragments AllGatherFragments(FractureEngine& engine, ncclComm_t comm, int world, hipStream_t stream)
 {
+    // A rank whose event failed must not leave the others waiting in a collective: its size word says so, and every rank
+    // throws after the size exchange.
     surtr_counts c;
-    int rc = surtr_event_counts(engine.Raw(), &c);
-    if (rc) throw Error(rc, "surtr_event_counts");
-    const uint64_t mine = surtr_event_blob_bytes(&c);
+    const int rc0 = surtr_event_counts(engine.Raw(), &c);
+    const uint64_t kFailed = ~(uint64_t)0;
+    const uint64_t mine = rc0 ? kFailed : (uint64_t)surtr_event_blob_bytes(&c);
     // 1. sizes
     DevBuf d_sizes((size_t)world * 8), d_mine(8);
     hip_ck(hipMemcpyAsync(d_mine.p, &mine, 8, hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
@@ -30,19 +32,33 @@ GatheredFragments AllGatherFragments(FractureEngine& engine, ncclComm_t comm, in
     std::vector<uint64_t> sizes(world);
     hip_ck(hipMemcpyAsync(sizes.data(), d_sizes.p, (size_t)world * 8, hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
     hip_ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (rc0) throw Error(rc0, "surtr_event_counts");
+    for (int r = 0; r < world; ++r) if (sizes[r] == kFailed) throw Error(SURTR_E_STATE, "the event of rank " + std::to_string(r) + " failed");
     uint64_t stride = 0;
     for (uint64_t s : sizes) stride = s > stride ? s : stride;
     stride = (stride + 255) & ~(uint64_t)255;
-    // 2. blobs, padded to the largest
+    // 2. blobs, padded to the largest.  k_pack runs on the ENGINE's stream (surtr_get_stream), the collective on the caller's:
+    // the padding is cleared on the engine's stream before the pack, and the caller's stream waits for the pack.
+    void* es = nullptr;
+    int rc = surtr_get_stream(engine.Raw(), &es);
+    if (rc) throw Error(rc, "surtr_get_stream");
+    hipStream_t estream = (hipStream_t)es;
     DevBuf d_blob(stride), d_all(stride * (size_t)world);
-    hip_ck(hipMemsetAsync(d_blob.p, 0, stride, stream), "hipMemsetAsync");
+    hip_ck(hipMemsetAsync(d_blob.p, 0, stride, estream), "hipMemsetAsync");
     rc = surtr_event_pack_dev(engine.Raw(), d_blob.p, stride);
-    if (rc) throw Error(rc, "surtr_event_pack_dev");
-    nccl_ck(ncclAllGather(d_blob.p, d_all.p, stride, ncclUint8, comm, stream), "ncclAllGather(blobs)");
+    hipEvent_t packed = nullptr;
+    hip_ck(hipEventCreateWithFlags(&packed, hipEventDisableTiming), "hipEventCreate");
+    hipError_t e1 = hipEventRecord(packed, estream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, packed, 0) : e1;
+    // (the collective is entered whatever happened above, so that no rank is left alone in it; errors are raised after it)
+    ncclResult_t nr = ncclAllGather(d_blob.p, d_all.p, stride, ncclUint8, comm, stream);
     GatheredFragments out;
     out.stride = stride; out.host.resize(stride * (size_t)world); out.counts.resize(world);
-    hip_ck(hipMemcpyAsync(out.host.data(), d_all.p, out.host.size(), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
-    hip_ck(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    hipError_t e3 = hipMemcpyAsync(out.host.data(), d_all.p, out.host.size(), hipMemcpyDeviceToHost, stream);
+    hipError_t e4 = hipStreamSynchronize(stream);
+    (void)hipEventDestroy(packed);
+    if (rc) throw Error(rc, "surtr_event_pack_dev");
+    hip_ck(e1, "hipEventRecord"); hip_ck(e2, "hipStreamWaitEvent"); nccl_ck(nr, "ncclAllGather(blobs)"); hip_ck(e3, "hipMemcpyAsync"); hip_ck(e4, "hipStreamSynchronize");
     for (int r = 0; r < world; ++r)
     {
         rc = surtr_blob_unpack_host(out.host.data() + (size_t)r * stride, sizes[r], &out.counts[r], nullptr);
