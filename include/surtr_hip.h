@@ -60,10 +60,14 @@ typedef struct surtr_counts {
     uint32_t n_idx;        /* triangle indices (render buffers) */
     uint32_t n_pairs;      /* (cell, piece) pairs processed */
     uint32_t status;       /* device-side status word, SURTR_OK or an error code */
-    uint32_t n_failed;     /* fragments on which a per-fragment task of the reference has no valid result: no triangles because
-                            * Poly::ExtractFaces does not terminate on them (Src/Poly.cpp:100-118), or the un-refitted Convex
-                            * because m_refittingTask's clip of it is no polyhedron (a one-way link, Src/Poly.cpp:484-493 through a
-                            * stale ID); frag_status names them.  The event itself is SURTR_OK. */
+    uint32_t n_failed;     /* THE DEGENERATE POLICY.  Where the reference leaves its own arrays -- a ring entry that names no vertex
+                            * (out of range, a removal mark read as a vertex), a link to a clipped vertex renumbered through a stale
+                            * or never-set ID (Src/Poly.cpp:484-493), an ExtractFaces walk that never ends (:100-118) -- nothing it
+                            * does afterwards is emulated; the unit is FLAGGED and the event stays SURTR_OK.  n_failed counts the
+                            * flags: a pair whose Mesh clip has no valid answer yields no fragment (surtr_pair_status names it); a
+                            * fragment whose refit has no valid answer keeps its un-refitted Convex, one whose faces cannot be
+                            * extracted has no triangles (frag_status names them).  Asked for one solid (surtr_clip_polyhedron,
+                            * surtr_refit_solid, ...), the call returns SURTR_E_TOPOLOGY instead. */
 } surtr_counts;
 
 /* Host-side view used by surtr_event_download: every pointer may be NULL to

@@ -121,6 +121,23 @@ def neighbours_from_mesh(pos, tris):
     return _solid(pos, off, nbr)
 
 
+
+def transform(solid, world):
+    """Poly::Transform (Src/Poly.cpp:580-585): every position through XMVector3TransformCoord(v, XMMatrixTranspose(M)) as
+    ExecuteFractureRoutine applies it before an event (Src/Surtr.cpp:1846-1851).  DirectXMath is not in the reference tree; its
+    published algorithm restated in float32: per row of `world` (4 x 4, row-major, translation in the last column)
+    x*m0 + (y*m1 + (z*m2 + m3)), multiply-then-add without contraction, then the divide by w.  numpy restatement (no C needed:
+    three multiply-adds per component)."""
+    p = np.asarray(solid["pos"], np.float32).reshape(-1, 3)
+    w = np.asarray(world, np.float32).reshape(4, 4)
+    r = []
+    for c in range(4):
+        t = (p[:, 2] * w[c, 2] + w[c, 3]).astype(np.float32)
+        t = (p[:, 1] * w[c, 1] + t).astype(np.float32)
+        r.append((p[:, 0] * w[c, 0] + t).astype(np.float32))
+    out = np.stack([(r[0] / r[3]).astype(np.float32), (r[1] / r[3]).astype(np.float32), (r[2] / r[3]).astype(np.float32)], 1)
+    return dict(solid, pos=out)
+
 def hull_normals(points, limit):
     pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
     bag = lib().orc_hull_normals(ctypes.c_int(pts.shape[0]), _p(pts), ctypes.c_int(limit))

@@ -7,11 +7,12 @@
 // order-free formulation follows.  Mostly the solid is gone a moment later (fewer than four vertices left, :497-499) and the
 // reference's answer is simply "empty".  This file is the last resort for such a solid when it is small: the whole clip again,
 // literally (bounding-box shortcut, snapshot of the rings, insertions, two-neighbour collapse, compaction), with fixed-stride
-// rings in the workgroup's global scratch.  Where the reference itself leaves its domain -- an index that is no vertex: out of
-// range, or a link to a clipped vertex that survives the compaction and is renumbered through an ID that was never set -- it
-// returns SURTR_E_TOPOLOGY, as before; a surviving link renumbered through a stale but valid ID is carried on like the reference
-// does (the result is the reference's, and no polyhedron: `stale_out` says so).  Found by scripts/fuzz_refracture_gpu.py, seed 555 case 110
-// (tests/golden/degenerate_walk_bound_convex.npz).
+// rings in the workgroup's global scratch.  THE DEGENERATE POLICY (frozen in round 3): where the reference itself leaves its
+// domain -- an index that is no vertex (out of range, a removal mark read as a vertex), or a link to a clipped vertex that
+// survives the compaction and would be renumbered through a stale or never-set ID -- this returns SURTR_E_TOPOLOGY and the
+// caller flags the fragment / pair; nothing the reference does after that point is emulated.  What stays: the reference's walk
+// bound (:389-394) and its "fewer than four vertices: empty" answers.  Found by scripts/fuzz_refracture_gpu.py, seed 555
+// case 110 (tests/golden/degenerate_walk_bound_convex.npz).
 #pragma once
 #include "clip_core.h"
 
@@ -54,14 +55,13 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
                                    bool ids_set = false)
 {
     uint32_t n = in.nv;
-    bool stale = false;
     if (n > S.capV) return SURTR_E_CAPACITY;
     for (uint32_t v = 0; v < n; ++v)
     {
         S.pos[3 * v] = in.pos[3 * v]; S.pos[3 * v + 1] = in.pos[3 * v + 1]; S.pos[3 * v + 2] = in.pos[3 * v + 2];
         const uint32_t deg = in.llen[v];
         if (deg > LIT_STRIDE) return SURTR_E_CAPACITY;
-        S.len[v] = deg; S.comp[v] = 1; S.id[v] = ids_set ? (int32_t)v : -1;
+        S.len[v] = deg; S.comp[v] = 1; S.id[v] = -1;
         for (uint32_t j = 0; j < deg; ++j) S.ring[v * LIT_STRIDE + j] = (in.nbr + in.loff[v])[j];
     }
     double lo[3] = {1.7976931348623157e308, 1.7976931348623157e308, 1.7976931348623157e308}, hi[3] = {-1.7976931348623157e308, -1.7976931348623157e308, -1.7976931348623157e308};
@@ -123,9 +123,8 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
             for (uint32_t j = 0; j < deg; ++j)
             {
                 const int32_t jn = S.ring[i * LIT_STRIDE + j];
-                // a removal mark that an insertion moved up into the part of the ring still to be visited: the reference reads
-                // comp[-1] there -- the word in front of its vertex array, which is not -1 -- and goes on
-                if (jn == -1) continue;
+                // (a removal mark that an insertion moved up into the part of the ring still to be visited is no vertex either:
+                // the reference reads comp[-1] there, outside its array -- undefined, flagged, not emulated)
                 if (!ok(jn, n1)) return SURTR_E_TOPOLOGY;
                 if (S.comp[jn] != -1) continue;
                 int32_t prev = (int32_t)i, cur = jn; uint32_t steps = 0;
@@ -191,13 +190,11 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
             {
                 const int32_t e = S.ring[i * LIT_STRIDE + j];
                 if (!ok(e, n1)) return SURTR_E_TOPOLOGY;
-                // A link to a clipped vertex that survived the relink is renumbered through that vertex's stale ID (:484-493):
-                // its index after the previous compaction of this call (the link then points at whatever vertex has that index
-                // now -- the reference carries on with it), or -1 if it was never compacted (no vertex: the reference's next
-                // access is out of bounds).  `stale` tells the caller that the result went through this.
-                const int32_t to = S.id[e];
-                if (S.comp[e] < 0) { stale = true; if (to < 0 || (uint32_t)to >= live) return SURTR_E_TOPOLOGY; }
-                S.ring[i * LIT_STRIDE + j] = to;
+                // A link to a clipped vertex that survived the relink would be renumbered through that vertex's stale ID
+                // (:484-493: an index of an earlier compaction, or one that was never set): whatever the reference returns
+                // after that is an accident of its memory.  Flagged, not emulated ("the degenerate policy").
+                if (S.comp[e] < 0) return SURTR_E_TOPOLOGY;
+                S.ring[i * LIT_STRIDE + j] = S.id[e];
             }
         }
         uint32_t w = 0;
@@ -216,7 +213,8 @@ __device__ inline int literal_clip(const SolidIn in, const uint32_t F, const flo
         if (n < 4u) { n = 0; break; }                                            // :497-499
     }
     *n_out = n;
-    if (stale_out != nullptr) *stale_out = stale && n != 0u;
+    (void)ids_set;
+    if (stale_out != nullptr) *stale_out = false;      // (kept for the callers' signature: a stale link is an error now)
     return 0;
 }
 

@@ -272,6 +272,14 @@ __global__ void k_place_cells_groups(uint32_t nfaces, const float* __restrict__ 
     planes[f] = plane_from_points(p, p + 3, p + 6);
 }
 
+// A pair whose Mesh clip has no valid answer in the reference (SURTR_E_TOPOLOGY: the degenerate policy of literal_clip.h) yields
+// no fragment, is counted in surtr_counts::n_failed and keeps its status for surtr_pair_status; the event goes on.  Any other
+// error is the event's.
+__device__ __forceinline__ void pair_failed(const Arena& A, int err)
+{
+    if (err == SURTR_E_TOPOLOGY) atomicAdd(&A.cursors[14], 1u); else atomicMax(&A.cursors[5], (uint32_t)err);
+}
+
 // ------------------------------------------------------------- arena output
 __device__ __attribute__((always_inline)) static inline bool arena_take(const Arena& A, Shared& sh, uint32_t nv, uint32_t nh, uint32_t nisl,
                                   uint32_t& voff, uint32_t& hoff, uint32_t& ioff)
@@ -957,7 +965,7 @@ __device__ __attribute__((noinline)) static int pair_global(Pieces P, uint32_t p
     if (err == 0 && !gone) err = clip_global(min, F, S, sh, consume);
     __syncthreads();
     if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;
-    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (threadIdx.x == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (threadIdx.x == 0) pair_failed(A, err); }
     if (threadIdx.x == 0) pairs[p] = rec;
     return err;
 }
@@ -1027,7 +1035,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pair_general(S
         return;
     }
     if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
-    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+    if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) pair_failed(A, err); }
     if (tid == 0) pairs[p] = rec;
 }
 
@@ -1220,7 +1228,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
             continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
-        if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
+        if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) pair_failed(A, err); }
         if (tid == 0) pairs[p] = rec;
     }
 }

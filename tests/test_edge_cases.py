@@ -65,7 +65,7 @@ def check_projective_transform(E, oracle):
         got = eng.download()
     finally:
         eng.close()
-    assert np.array_equal(got["mesh_pos"], ops.transform_ref(box, w)["pos"])
+    assert np.array_equal(got["mesh_pos"], oracle.transform(box, w)["pos"])
 
 
 def check_whole_piece_survives_and_vanishes(E, oracle):

@@ -254,15 +254,16 @@ def test_image_arena_exhaustion_falls_back(emul_engine, oracle, monkeypatch):
 def test_degenerate_ach_of_a_box_is_refused(emul_engine):
     """Found by scripts/fuzz_gpu.py: the ACH of an axis-aligned box has slabs that coincide with the box faces up to
     rounding and near-duplicate vertices; a cell plane then leaves a clipped vertex linked from a surviving one, where the
-    reference indexes with ID = -1 (Src/Poly.cpp:464-495).  The engine must answer SURTR_E_TOPOLOGY, not crash."""
+    reference indexes with ID = -1 (Src/Poly.cpp:464-495).  The engine must flag the pair (SURTR_E_TOPOLOGY in its status), not crash."""
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "degenerate_ach_cube.npz"))
     eng = emul_engine.Engine(0)
     eng.upload_pieces([{"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}],
                       [{"pos": d["conv_pos"], "off": d["conv_off"], "nbr": d["conv_nbr"]}])
     eng.upload_planes(np.uint32([0, d["planes"].shape[0]]), d["planes"])
-    with pytest.raises(emul_engine.SurtrError) as e:
-        eng.fracture_event(0, 1, flags=3)
-    assert e.value.code == emul_engine.E_TOPOLOGY
+    # the degenerate policy (DESIGN section 3.7): the pair is flagged and yields no fragment, the event goes on
+    c = eng.fracture_event(0, 1, flags=3)
+    assert c.status == 0 and c.n_frag == 0 and c.n_failed == 1
+    assert eng.pair_status(1).tolist() == [emul_engine.E_TOPOLOGY]
     # the context stays usable
     sc = scenes.cube_scene(8)
     eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
@@ -437,8 +438,8 @@ def test_faces_second_tier_and_workgroup_budget(emul_engine, oracle, monkeypatch
 def check_refit_invalid_in_reference(E, oracle):
     """Refracture fuzz seed 555002, case 82, fragment 536 (tests/golden/refit_invalid_in_reference.npz: Mesh and Convex of nine
     vertices each): the reference's refit leaves a link to a clipped vertex, renumbers it through that vertex's stale ID
-    (Src/Poly.cpp:484-493) and carries on with a Convex of seven vertices that has a one-way link.  The engine's parallel
-    clipper refuses the walk, its literal clipper follows the reference: same seven vertices, same links, event SURTR_OK."""
+    (Src/Poly.cpp:484-493) and carries on with a Convex of seven vertices that has a one-way link.  The engine flags the
+    fragment instead of following the stale ID (it keeps its un-refitted Convex), event SURTR_OK."""
     from helpers import solid_is_polyhedron
     d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refit_invalid_in_reference.npz"))
     mesh = {"pos": d["mesh_pos"], "off": d["mesh_off"], "nbr": d["mesh_nbr"]}
@@ -449,22 +450,24 @@ def check_refit_invalid_in_reference(E, oracle):
     cube = scenes.cube_scene(8)
     eng = E.Engine(0)
     try:
-        got = eng.refit_solid(mesh, conv)
-        assert np.array_equal(got["off"], ref["off"]) and np.array_equal(got["nbr"], ref["nbr"])
-        assert np.allclose(got["pos"], ref["pos"], rtol=RTOL, atol=1e-6)
-        # among other fragments
+        # asked for that one solid, the engine says that there is no valid answer (the degenerate policy, DESIGN section 3.7:
+        # the stale ID is not followed)
+        with pytest.raises(E.SurtrError) as e:
+            eng.refit_solid(mesh, conv)
+        assert e.value.code == E.E_TOPOLOGY
+        # among other fragments: flagged, keeps the Convex it had, the others are refitted
         eng.load_fragments([cube["mesh"], mesh, cube["mesh"]], [cube["convex"], conv, cube["convex"]])
         eng.event_refit()
         c = eng.event_counts()
         ev = eng.download()
-        assert c.status == 0 and c.n_failed == 0 and not ev["frag_status"].any()
+        assert c.status == 0 and c.n_failed == 1 and ev["frag_status"].tolist() == [0, E.E_TOPOLOGY, 0]
         r1 = fragment(ev, 1, "conv")
-        assert np.array_equal(r1["off"], ref["off"]) and np.array_equal(r1["nbr"], ref["nbr"])
+        assert np.array_equal(r1["off"], conv["off"]) and np.array_equal(r1["nbr"], conv["nbr"]) and np.array_equal(r1["pos"], conv["pos"])
         ref0 = oracle.refit(cube["convex"], cube["mesh"], 4)
         for k in (0, 2):
             r = fragment(ev, k, "conv")
             assert np.array_equal(r["off"], ref0["off"]) and np.array_equal(r["nbr"], ref0["nbr"])
-        # the invalid Convex goes on through the triangulation of the event (its Mesh is what is triangulated)
+        # the flagged fragment goes on through the triangulation of the event (its Mesh is what is triangulated)
         eng.event_triangulate()
         assert eng.event_counts().status == 0
     finally:

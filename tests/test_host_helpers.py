@@ -150,8 +150,9 @@ def test_obj_reader_conventions_and_writer(tmp_path):
     assert lines[0] == "o cell0_piece0_island0" and lines[4] == "f 1 2 3" and lines[5] == "o cell1_piece0_island0" and lines[9] == "f 4 6 5"
 
 
-def check_device_rings(E):
-    """surtr_neighbors_from_mesh_dev == surtr_neighbors_from_mesh (ring order and rotation), and the same refusals."""
+def check_device_rings(E, oracle=None):
+    """surtr_neighbors_from_mesh_dev == oracle.neighbours_from_mesh == surtr_neighbors_from_mesh (ring order and rotation), and
+    the same refusals."""
     from surtr_amd import meshgen
     eng = E.Engine(0)
     try:
@@ -159,6 +160,9 @@ def check_device_rings(E):
             want = E.neighbors_from_mesh(v, t)
             got, _ = eng.neighbors_from_mesh(v, t)
             assert np.array_equal(got["off"], want["off"]) and np.array_equal(got["nbr"], want["nbr"])
+            if oracle is not None:
+                o = oracle.neighbours_from_mesh(v, t)
+                assert np.array_equal(got["off"], o["off"]) and np.array_equal(got["nbr"], o["nbr"])
         v, t = meshgen.cube()
         bad = t.copy(); bad[0] = bad[0][::-1]                 # one triangle wound the other way: a directed edge twice
         with pytest.raises(E.SurtrError) as e:
@@ -171,5 +175,5 @@ def check_device_rings(E):
         eng.close()
 
 
-def test_device_rings_emulated(emul_engine):
-    check_device_rings(emul_engine)
+def test_device_rings_emulated(emul_engine, oracle):
+    check_device_rings(emul_engine, oracle)

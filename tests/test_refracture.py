@@ -40,6 +40,9 @@ def _refracture(engine_mod, oracle, n_first, n_second, nu, nv):
     eng.place_cells_groups(rs["group_cell_off"], rs["scales"], rs["shifts"])
     c = eng.fracture_pairs(rs["pair_cell"], rs["pair_piece"], flags=3)
     got = eng.download()
+    # pairs whose Mesh clip has no valid answer in the reference (helpers.assert_event_equal_flagged)
+    ps = eng.pair_status(len(rs["pair_cell"]))
+    got["flagged_pairs"] = [(int(rs["pair_cell"][i]), int(rs["pair_piece"][i])) for i in np.nonzero(ps)[0]]
     eng.close()
     # oracle: piece by piece, its own cells, fragment-major
     parts = []

@@ -73,19 +73,6 @@ def _world_matrices(n, seed=3):
     return np.asarray(out, np.float32)
 
 
-def transform_ref(solid, w):
-    """Poly::Transform restated (Src/Poly.cpp:580-585 + XMVector3TransformCoord): float32, multiply-then-add, divide by w."""
-    p = solid["pos"].astype(np.float32)
-    w = w.astype(np.float32)
-    r = []
-    for c in range(4):
-        t = (p[:, 2] * w[c, 2] + w[c, 3]).astype(np.float32)
-        t = (p[:, 1] * w[c, 1] + t).astype(np.float32)
-        r.append((p[:, 0] * w[c, 0] + t).astype(np.float32))
-    out = np.stack([(r[0] / r[3]).astype(np.float32), (r[1] / r[3]).astype(np.float32), (r[2] / r[3]).astype(np.float32)], 1)
-    return dict(solid, pos=out)
-
-
 def check_transform_pieces(E, oracle):
     """ExecuteFractureRoutine's pre-transform (Src/Surtr.cpp:1846-1851): pieces moved on the device, then an event."""
     sc, planes, ev = _blob_event(oracle, 6)
@@ -93,8 +80,8 @@ def check_transform_pieces(E, oracle):
     meshes = [fragment(ev, k, "mesh") for k in range(n)]
     convs = [fragment(ev, k, "conv") for k in range(n)]
     W = _world_matrices(n)
-    m2 = [transform_ref(m, W[k]) for k, m in enumerate(meshes)]
-    c2 = [transform_ref(c, W[k]) for k, c in enumerate(convs)]
+    m2 = [oracle.transform(m, W[k]) for k, m in enumerate(meshes)]
+    c2 = [oracle.transform(c, W[k]) for k, c in enumerate(convs)]
     # one pattern over the box of everything after the move
     allp = np.concatenate([m["pos"] for m in m2])
     lo, hi = allp.min(0), allp.max(0)
