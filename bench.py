@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--cells", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
+    ap.add_argument("--equal-blocks", action="store_true", help="strong sharding in equal-sized cell blocks instead of cost-balanced ones")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, all-gather) with one rank")
     args = ap.parse_args()
     # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner under
@@ -128,7 +129,19 @@ def main():
         eng.upload_pieces([sc["mesh"]], [sc["convex"]])
         eng.upload_pieces([sc["mesh"]], [sc["convex"]])       # second call: steady state of the piece pool
         setup_ms["upload_ms"], setup_ms["upload_allocs"] = eng.upload_stats()
-        cb, ce = (0, sc["n_cells"]) if mode == "weak" else engine.cell_block(rank, world, sc["n_cells"])
+        if mode == "weak" or world == 1:
+            cb, ce = 0, sc["n_cells"]
+        elif args.equal_blocks:
+            cb, ce = engine.cell_block(rank, world, sc["n_cells"])
+        else:
+            # strong sharding in contiguous, cost-balanced cell blocks: every rank runs the whole event once at set-up (inputs
+            # are replicated, so all ranks see the same per-cell costs and compute the same cuts); order is untouched
+            eng.place_cells(sc["scale"], sc["translate"])
+            eng.fracture_event(0, sc["n_cells"], flags=flags)
+            costs = eng.pair_costs(sc["n_cells"]).astype(np.float64)      # one piece: pair = cell
+            cuts = engine.balanced_blocks(costs, world)
+            cb, ce = cuts[rank], cuts[rank + 1]
+            setup_ms["block_cost_share"] = float(costs[cb:ce].sum() / max(costs.sum(), 1.0))
         # sizing pass: blob capacity for the timed loop (sizes are identical every step: same inputs)
         eng.place_cells(sc["scale"], sc["translate"])
         counts = eng.fracture_event(cb, ce, flags=flags)
@@ -262,7 +275,7 @@ def main():
                                    "1 piece (mesh + its ACH convex), refit + triangulation on" % sc["n_cells"],
                        "cells": sc["n_cells"] * (world if args.scaling == "weak" else 1), "fragments": total_frag,
                        "parallelism": ("%d ranks x one %d-cell event each, one all-gather" % (world, sc["n_cells"])) if args.scaling == "weak"
-                                      else ("one event, cells sharded x%d in contiguous blocks, one all-gather" % world if world > 1 else "one GPU")},
+                                      else ("one event, cells sharded x%d in contiguous %s blocks, one all-gather" % (world, "equal-sized" if args.equal_blocks else "cost-balanced") if world > 1 else "one GPU")},
             "ms_per_fracture_event": ms_per_step,
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
             "roofline": {"kernel": "k_clip_pairs", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -118,6 +118,11 @@ int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128]);
 /* Diagnostic: the status of every pair of the last event (0, or the SURTR_E_* code that pair raised), in pair order
  * (cell-major for surtr_fracture_event, list order for surtr_fracture_pairs).  Works after an event that failed. */
 int surtr_pair_status(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* status);
+/* A cost estimate per pair of the last event (band vertices its Mesh clip worked on + vertices it produced; small for a pair
+ * whose Convex came out empty): what a sharded run balances its contiguous rank blocks with ("optional cost
+ * balancing must not change output order"; the reference hands one task per cell to whichever pool thread is free,
+ * Src/Surtr.cpp:2129-2131). */
+int surtr_event_pair_costs(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* cost);
 
 /* ---- inputs ------------------------------------------------------------ */
 /* Replaces compound.PieceVec (Inc/Surtr.h:113-134): n pieces, each a (Convex, Mesh)

@@ -3479,6 +3479,27 @@ int surtr_pair_status(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* status)
     return SURTR_OK;
 }
 
+int surtr_event_pair_costs(surtr_ctx* ctx, uint32_t n_pairs, uint32_t* cost)
+{
+    if (!ctx || !cost) return SURTR_E_INVALID;
+    if (!ctx->have_event || n_pairs > ctx->cap_pairs) return SURTR_E_STATE;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<PairRec> recs(n_pairs);
+    if (n_pairs) HIPCHK(hipMemcpy(recs.data(), ctx->d_pairs, (size_t)n_pairs * sizeof(PairRec), hipMemcpyDeviceToHost));
+    // what the Mesh clip of the pair worked on: vertices of the band (the image k_prep_pairs left; the whole Mesh when the pair
+    // had none) + the vertices that came out, as a proxy for the cut points it went through.  A pair whose Convex came out empty
+    // costs its Convex clip only.
+    for (uint32_t i = 0; i < n_pairs; ++i)
+    {
+        const PairRec& r = recs[i];
+        uint32_t c = 8u;
+        if (r.cv_n != 0) c += (r.img_fmt == IMG_NARROW || r.img_fmt == IMG_WIDE ? r.img_n : 256u) + 4u * r.mv_n + 64u;
+        cost[i] = c;
+    }
+    return SURTR_OK;
+}
+
 int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128])
 {
     if (!ctx || !out) return SURTR_E_INVALID;

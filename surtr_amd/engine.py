@@ -147,6 +147,12 @@ class Engine:
         self._ck(lib().surtr_pair_status(self._h, ctypes.c_uint32(n_pairs), _p(out)))
         return out
 
+    def pair_costs(self, n_pairs):
+        """Cost estimate per pair of the last event (include/surtr_hip.h: surtr_event_pair_costs)."""
+        out = np.zeros(n_pairs, dtype=np.uint32)
+        self._ck(lib().surtr_event_pair_costs(self._h, ctypes.c_uint32(n_pairs), _p(out)))
+        return out
+
     def queue_stats(self):
         """Device-side counters of the last event (include/surtr_hip.h: surtr_queue_stats)."""
         out = (ctypes.c_uint32 * 128)()
@@ -457,6 +463,27 @@ def merge_fragments(parts):
 def cell_block(rank, world, n_cells):
     """Contiguous cell block of a rank: [floor(r*C/G), floor((r+1)*C/G))."""
     return (rank * n_cells) // world, ((rank + 1) * n_cells) // world
+
+
+def balanced_blocks(costs, world):
+    """Cut points of `world` CONTIGUOUS blocks of units (cells of an event, or the pairs of a pair list) with costs `costs`:
+    block r = [cuts[r], cuts[r + 1]).  Order is untouched -- results concatenated in rank order are still in unit order
+    (Src/Surtr.cpp:2133-2146) -- only where the cuts fall changes: cut r sits where the running cost passes r / world of the total
+    (SURVEY.md section 8e).  Deterministic in its inputs, so every rank computes the same cuts from the same costs."""
+    c = np.asarray(costs, np.float64)
+    n = c.shape[0]
+    if n == 0 or world <= 1:
+        return [0] + [n] * max(world, 1)
+    cum = np.concatenate([[0.0], np.cumsum(c)])
+    cuts = [0]
+    for r in range(1, world):
+        k = int(np.searchsorted(cum, cum[-1] * r / world, side="left"))
+        # the unit whose cost straddles the target goes to the side that leaves the smaller excess
+        if k > 0 and k <= n and abs(cum[k - 1] - cum[-1] * r / world) <= abs(cum[min(k, n)] - cum[-1] * r / world):
+            k -= 1
+        cuts.append(min(max(k, cuts[-1]), n))
+    cuts.append(n)
+    return cuts
 
 
 def pair_block(rank, world, n_pairs):

@@ -128,7 +128,125 @@ static void api_dump(const char* path, const std::vector<Fragment>& frags, const
         for (size_t i = 0; i < planes.size(); ++i) fprintf(f, "%s%.9g, %.9g, %.9g, %.9g", i ? ", " : "", planes[i].x, planes[i].y, planes[i].z, planes[i].w);
         fprintf(f, "], "); js_solid(f, "box", box); fprintf(f, "}");
     }
-    fprintf(f, "]}\n");
+    fprintf(f, "]");
+    // Surtr::DoFracture (Src/Surtr.cpp:1885-1959) with PartialFracture on the fragments of the event as one compound: what it
+    // regrouped (un-refitted Convex solids, cells, the impact sphere) and what came out (bind sets, refitted pieces), plus the
+    // three tasks through their reference signatures (Inc/Surtr.h:270-272)
+    {
+        auto valid = [](const Poly::Polyhedron& p) {
+            if (p.size() < 4) return false;
+            for (size_t v = 0; v < p.size(); ++v)
+            {
+                if (p[v].NeighborVertexVec.size() < 3) return false;
+                for (int u : p[v].NeighborVertexVec)
+                {
+                    if (u < 0 || (size_t)u >= p.size() || (size_t)u == v) return false;
+                    const auto& r = p[(size_t)u].NeighborVertexVec;
+                    if (std::find(r.begin(), r.end(), (int)v) == r.end()) return false;
+                }
+            }
+            return true;
+        };
+        Compound comp;
+        for (const auto& fr : frags) if (valid(fr.piece_data.Mesh) && valid(fr.piece_data.Convex)) comp.PieceVec.push_back(fr.piece_data);
+        FractureEngine& eng = DefaultEngine();
+        eng.GenerateVoronoi(5, 46354 + 7);
+        const float maxAxis = std::max(ext.x, std::max(ext.y, ext.z));
+        FractureArgs args; args.PartialFracture = true;
+        args.ImpactPosition = Vector3(cen.x + 0.2f * ext.x, cen.y + 0.1f * ext.y, cen.z); args.ImpactRadius = 0.3f * maxAxis;
+        std::vector<Vector3> sphere;
+        for (int i = 0; i < 96; ++i)       // a Fibonacci sphere stands for m_spherePointCloud
+        {
+            const double z = 1.0 - 2.0 * (i + 0.5) / 96.0, r = std::sqrt(1.0 - z * z), a = i * 2.399963229728653;
+            sphere.emplace_back((float)(r * std::cos(a)), (float)(r * std::sin(a)), (float)z);
+        }
+        FractureEngine::FractureTrace tr;
+        const std::vector<Compound> res = eng.DoFracture(comp, maxAxis, args, sphere, &tr);
+        fprintf(f, ", \"do_fracture\": {\"n_pieces_in\": %zu, \"n_outside\": %u, \"origin\": [%.9g, %.9g, %.9g], \"radius\": %.9g, \"cloud\": [",
+                comp.PieceVec.size(), tr.nOutside, args.ImpactPosition.x, args.ImpactPosition.y, args.ImpactPosition.z, args.ImpactRadius);
+        for (size_t i = 0; i < sphere.size(); ++i)
+        {
+            Vector3 v = sphere[i];
+            v.x *= args.ImpactRadius; v.y *= args.ImpactRadius; v.z *= args.ImpactRadius;
+            v.x += args.ImpactPosition.x; v.y += args.ImpactPosition.y; v.z += args.ImpactPosition.z;
+            fprintf(f, "%s%.9g, %.9g, %.9g", i ? ", " : "", v.x, v.y, v.z);
+        }
+        fprintf(f, "], \"piece_cell\": [");
+        for (size_t i = 0; i < tr.PieceCell.size(); ++i) fprintf(f, "%s%d", i ? ", " : "", tr.PieceCell[i]);
+        fprintf(f, "], \"convex\": [");
+        for (size_t i = 0; i < tr.Convex.size(); ++i) { fprintf(f, "%s{", i ? ", " : ""); js_solid(f, "s", tr.Convex[i]); fprintf(f, "}"); }
+        fprintf(f, "], \"binds\": [");
+        for (size_t c = 0; c < tr.CompoundBind.size(); ++c)
+        {
+            fprintf(f, "%s[", c ? ", " : "");
+            bool first = true;
+            for (int pc : tr.CompoundBind[c]) { fprintf(f, "%s%d", first ? "" : ", ", pc); first = false; }
+            fprintf(f, "]");
+        }
+        // the pieces that came out, compound by compound (refitted)
+        fprintf(f, "], \"pieces_out\": [");
+        bool firstp = true;
+        for (const auto& cpd : res)
+            for (const auto& pc : cpd.PieceVec) { fprintf(f, "%s{", firstp ? "" : ", "); js_solid(f, "mesh", pc.Mesh); fprintf(f, ", "); js_solid(f, "convex", pc.Convex); fprintf(f, "}"); firstp = false; }
+        fprintf(f, "]");
+        // the set functions on their own, from the bind sets of ApplyFracture (bind 0 = the skipped pieces, one bind per cell)
+        {
+            CompoundInfo info;
+            for (const auto& cv : tr.Convex) info.PieceVec.emplace_back(cv, Poly::Polyhedron());
+            info.CompoundBind.emplace_back();
+            for (size_t i = 0; i < tr.PieceCell.size(); ++i)
+            {
+                if (tr.PieceCell[i] < 0) { info.CompoundBind[0].insert((int)i); continue; }
+                if (i == 0 || tr.PieceCell[i] != tr.PieceCell[i - 1] || tr.PieceCell[i - 1] < 0) info.CompoundBind.emplace_back();
+                info.CompoundBind.back().insert((int)i);
+            }
+            std::vector<Vector3> cloud = sphere;
+            for (auto& v : cloud) { v.x *= args.ImpactRadius; v.y *= args.ImpactRadius; v.z *= args.ImpactRadius; v.x += args.ImpactPosition.x; v.y += args.ImpactPosition.y; v.z += args.ImpactPosition.z; }
+            MergeOutOfImpact(info, cloud, args.ImpactPosition, args.ImpactRadius);
+            HandleConvexIsland(info);
+            fprintf(f, ", \"binds_by_set_functions\": [");
+            for (size_t c = 0; c < info.CompoundBind.size(); ++c)
+            {
+                fprintf(f, "%s[", c ? ", " : "");
+                bool first = true;
+                for (int pc : info.CompoundBind[c]) { fprintf(f, "%s%d", first ? "" : ", ", pc); first = false; }
+                fprintf(f, "]");
+            }
+            fprintf(f, "]");
+        }
+        // m_fractureTask / m_refittingTask / m_initCompoundTask through their reference signatures, on one placed cell
+        {
+            std::vector<Piece*> target;
+            for (size_t i = 0; i < comp.PieceVec.size() && i < 6; ++i) target.push_back(new Piece(comp.PieceVec[i].Convex, comp.PieceVec[i].Mesh));
+            VMACH::Polygon3D cell = cells[0];
+            cell.Scale(ext); cell.Translate(cen);
+            std::set<int> outside; outside.insert(1);
+            std::vector<Piece*> got = FractureTask(cell, target, outside);
+            fprintf(f, ", \"tasks\": {\"cell_planes\": [");
+            for (size_t i = 0; i < cell.FaceVec.size(); ++i) fprintf(f, "%s%.9g, %.9g, %.9g, %.9g", i ? ", " : "", cell.FaceVec[i].FacePlane.x, cell.FaceVec[i].FacePlane.y, cell.FaceVec[i].FacePlane.z, cell.FaceVec[i].FacePlane.w);
+            fprintf(f, "], \"target\": [");
+            for (size_t i = 0; i < target.size(); ++i) { fprintf(f, "%s{", i ? ", " : ""); js_solid(f, "mesh", target[i]->Mesh); fprintf(f, ", "); js_solid(f, "convex", target[i]->Convex); fprintf(f, "}"); }
+            fprintf(f, "], \"fractured\": [");
+            for (size_t i = 0; i < got.size(); ++i) { fprintf(f, "%s{", i ? ", " : ""); js_solid(f, "mesh", got[i]->Mesh); fprintf(f, ", "); js_solid(f, "convex", got[i]->Convex); fprintf(f, "}"); }
+            fprintf(f, "], \"refitted\": [");
+            for (size_t i = 0; i < got.size(); ++i) { RefittingTask(got[i]); fprintf(f, "%s{", i ? ", " : ""); js_solid(f, "convex", got[i]->Convex); fprintf(f, "}"); }
+            fprintf(f, "], \"init\": [");
+            for (size_t i = 0; i < got.size(); ++i)
+            {
+                Poly::Extract* ex = Poly::ExtractFaces(got[i]->Convex);
+                const InitCompoundResult r = InitCompoundTask(got[i], ex, false);
+                delete ex;
+                fprintf(f, "%s{\"points\": %zu, \"nv\": %zu, \"idx\": [", i ? ", " : "", r.ConvexPoints.size(), r.Mesh.vertexData.size());
+                for (size_t q = 0; q < r.Mesh.indexData.size(); ++q) fprintf(f, "%s%u", q ? ", " : "", r.Mesh.indexData[q]);
+                fprintf(f, "]}");
+            }
+            fprintf(f, "]}");
+            for (Piece* p : target) delete p;
+            for (Piece* p : got) delete p;
+        }
+        fprintf(f, "}");
+    }
+    fprintf(f, "}\n");
     fclose(f);
 }
 
@@ -175,13 +293,13 @@ int main(int argc, char** argv)
         if (ach) frags = eng.PrepareFracture(verts, tris, seeds);
         else
         {
-            eng.SetPattern(FractureEngine::GenerateVoronoi(seeds));
+            eng.SetPattern(eng.GenerateVoronoi(seeds));
             eng.PlacePattern(ext, cen);
             Compound comp; comp.PieceVec.push_back(piece);
             eng.SetCompound(comp);
             frags = eng.ApplyFracture();
         }
-        if (!dump.empty()) api_dump(dump.c_str(), frags, FractureEngine::GenerateVoronoi(seeds), ext, cen);
+        if (!dump.empty()) api_dump(dump.c_str(), frags, eng.GenerateVoronoi(seeds), ext, cen);
         const surtr_counts c = eng.LastCounts();
         printf("{\"mesh\": \"%s\", \"verts\": %zu, \"tris\": %zu, \"cells\": %d, \"fragments\": %u, \"mesh_verts\": %u, \"mesh_nbrs\": %u, "
                "\"conv_verts\": %u, \"indices\": %u}\n", mesh.c_str(), verts.size(), tris.size() / 3, cells, c.n_frag, c.mesh_verts,

@@ -85,7 +85,7 @@ static int run_rank(int rank, int world, int cells, int nu, int nv, int steps, c
         Piece piece;
         Poly::InitPolyhedron(piece.Mesh, verts, Poly::ExtractNeighborFromMesh(verts, tris));
         piece.Convex = eng.BuildACH(verts);
-        eng.SetPattern(FractureEngine::GenerateVoronoi(seeds));       // inputs are replicated on every rank
+        eng.GenerateVoronoi(seeds);       // built on the device and installed as the pattern; inputs are replicated on every rank
         eng.PlacePattern(ext, cen);
         Compound comp; comp.PieceVec.push_back(piece);
         eng.SetCompound(comp);

@@ -126,12 +126,45 @@ std::vector<Vector3> GenerateICHNormal(const std::vector<Vector3>& vertices, int
 void LoadModelData(const std::string& fileName, const Vector3& scale, const Vector3& translate, std::vector<Vector3>& vertices,
                    std::vector<int>& indices);
 
-struct Piece { Poly::Polyhedron Convex, Mesh; };            // Inc/Surtr.h:113-119
+struct Piece                                                // Inc/Surtr.h:113-119 (the reference heap-allocates them: Piece*)
+{
+    Poly::Polyhedron Convex, Mesh;
+    Piece() = default;
+    Piece(const Poly::Polyhedron& convex, const Poly::Polyhedron& mesh) : Convex(convex), Mesh(mesh) {}
+};
 struct Compound { std::vector<Piece> PieceVec; };           // Inc/Surtr.h:121-127 (value semantics: no leaks)
 // Inc/Surtr.h:129-134: pieces + bind sets (CompoundBind[0] = the pieces outside the impact).
 struct CompoundInfo { std::vector<Piece> PieceVec; std::vector<std::set<int>> CompoundBind; };
 
+// Surtr::FractureArgs, the members the event reads (Inc/Surtr.h:90-110; Src/Surtr.cpp:1885-1912).
+struct FractureArgs
+{
+    bool PartialFracture = false;
+    Vector3 ImpactPosition;
+    float ImpactRadius = 1.f;
+    int Seed = 46354;
+};
+
 struct FragmentRender { std::vector<VertexNormalColor> vertexData; std::vector<uint32_t> indexData; };
+
+// Surtr::ConvexOutOfSphere (Src/Surtr.cpp:2415-2458); `extract` = ExtractFaces(polyhedron) (derived again inside).
+bool ConvexOutOfSphere(const Poly::Polyhedron& polyhedron, const Poly::Extract* extract, const std::vector<Vector3>& spherePointCloud,
+                       const Vector3 origin, const float radius);
+// Surtr::MergeOutOfImpact (Src/Surtr.cpp:2368-2403): pieces of the compounds 1.. that are out of the sphere move to compound 0;
+// compounds left empty are removed.
+void MergeOutOfImpact(CompoundInfo& compoundInfo, const std::vector<Vector3>& spherePointCloud, const Vector3 origin, const float radius);
+// Surtr::HandleConvexIsland (Src/Surtr.cpp:2203-2366): every compound is split into the groups of pieces that touch through a
+// pair of opposite, overlapping faces; the first group stays, the others are appended.
+void HandleConvexIsland(CompoundInfo& compoundInfo);
+
+// The three per-Piece tasks with the reference's EXACT signatures (Inc/Surtr.h:270-272: pointer semantics; what they return is
+// the caller's, as Src/Surtr.cpp:1494,1499 `new Piece`), on the default engine.  m_initCompoundTask's result pair
+// <PxConvexMeshGeometry, DynamicMesh*> needs PhysX and D3D12: InitCompoundResult holds what those two are built from.
+std::vector<Piece*> FractureTask(const VMACH::Polygon3D& voroPoly, const std::vector<Piece*>& targetPieceVec, const std::set<int>& outside);
+void RefittingTask(Piece* piece);
+struct InitCompoundResult { std::vector<Vector3> ConvexPoints; FragmentRender Mesh; };
+InitCompoundResult InitCompoundTask(const Piece* piece, const Poly::Extract* extract, bool renderConvex);
+
 struct Fragment { int cell, piece, island; Piece piece_data; FragmentRender render; int status = 0; };
 
 // One engine per GPU (wraps surtr_ctx).  Mirrors the calls of Surtr::DoFracture (Src/Surtr.cpp:1885-1959).
@@ -145,8 +178,16 @@ public:
 
     // Fracture pattern in pattern space (GenerateFracturePattern / GenerateVoronoi, Src/Surtr.cpp:2003-2096).
     void SetPattern(const std::vector<VMACH::Polygon3D>& voroPolyVec);
-    // Pattern from seeds through the canonical Voronoi builder (voro++ replacement).
-    static std::vector<VMACH::Polygon3D> GenerateVoronoi(const std::vector<Vector3>& cellPointVec);
+    // Surtr::GenerateVoronoi(cellPointVec) (Src/Surtr.cpp:2003-2070; voro++ replaced by the canonical cell of DESIGN section 5)
+    // ON THE DEVICE: surtr_build_cells, which also installs the cells as this engine's pattern, + surtr_download_cells.
+    std::vector<VMACH::Polygon3D> GenerateVoronoi(const std::vector<Vector3>& cellPointVec);
+    // Surtr::GenerateVoronoi(cellCnt) (Src/Surtr.cpp:1984-2001): mt19937(seed), uniform(-0.5, 0.5) in x, y, z draw order.
+    std::vector<VMACH::Polygon3D> GenerateVoronoi(int cellCnt, int seed = 46354);
+    // Surtr::GenerateFracturePattern (Src/Surtr.cpp:2072-2096): exponential length (clamped to [1e-12, 0.5]) x normalised
+    // uniform(-1, 1)^3 direction.
+    std::vector<VMACH::Polygon3D> GenerateFracturePattern(int cellCount, double mean, int seed = 46354);
+    // the same cells from the host builder (surtr_voronoi_cells): the CPU-tier cross-check of the device builder
+    static std::vector<VMACH::Polygon3D> GenerateVoronoiHost(const std::vector<Vector3>& cellPointVec);
     // voro.Scale(scale); voro.Translate(translate) for every cell (Src/Surtr.cpp:1799-1803, 1891-1896).
     void PlacePattern(const Vector3& scale, const Vector3& translate);
     void SetCompound(const Compound& compound);
@@ -176,11 +217,22 @@ public:
     Poly::Extract ExtractFaces(const Poly::Polyhedron& polyhedron);
     FragmentRender RenderPolyhedron(const Poly::Polyhedron& poly, bool isConvex, const Vector3& color);
     Poly::Polyhedron TransformSolid(const Poly::Polyhedron& polyhedron, const Matrix& matrix);
+    // What DoFracture regrouped (for tests and tools): the un-refitted Convex solids in piece order (the compound's pieces the
+    // event skipped, ascending, then the event's fragments), the cell of every piece (-1: skipped), the bind sets found.
+    struct FractureTrace { std::vector<Poly::Polyhedron> Convex; std::vector<int> PieceCell; uint32_t nOutside = 0; std::vector<std::set<int>> CompoundBind; };
+    // Surtr::DoFracture (Src/Surtr.cpp:1885-1959) on the device, in the reference's order: pattern scaled by 2 * maxAxisScale
+    // and moved to the impact, sphere cloud scaled by the radius and moved to the impact, ApplyFracture (pieces out of the
+    // sphere are skipped when PartialFracture), MergeOutOfImpact (when PartialFracture), HandleConvexIsland -- both on the
+    // un-refitted Convex solids, surtr_event_regroup --, Refitting (surtr_event_refit), one Compound per bind set.  The
+    // pattern is the engine's (SetPattern / GenerateVoronoi / GenerateFracturePattern), in pattern space.
+    std::vector<Compound> DoFracture(const Compound& targetCompound, float maxAxisScale, const FractureArgs& args,
+                                     const std::vector<Vector3>& spherePointCloud, FractureTrace* trace = nullptr);
     surtr_counts LastCounts() const { return counts_; }
     surtr_ctx* Raw() { return ctx_; }
 
 private:
     void check(int rc, const char* what);
+    std::vector<Fragment> download_fragments(bool render);
     surtr_ctx* ctx_ = nullptr;
     uint32_t n_cells_ = 0, n_pieces_ = 0;
     surtr_counts counts_{};

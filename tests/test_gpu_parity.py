@@ -428,6 +428,43 @@ def test_cpp_api_surface(gpu_engine, oracle):
         same(solid(cc["by_polygon"]), solid(cc["by_planes"]))
         same(solid(cc["by_polygon"]), oracle.clip(solid(cc["box"]), np.array(cc["planes"], np.float32).reshape(-1, 4)))
         assert solid(cc["by_polygon"])["pos"].shape[0] >= 4
+    # Surtr::DoFracture with PartialFracture (Src/Surtr.cpp:1885-1959) on the device path: the bind sets against the oracle's
+    # ApplyFracture / MergeOutOfImpact / HandleConvexIsland on the same un-refitted Convex solids, the pieces that came out
+    # against the oracle's refit; MergeOutOfImpact + HandleConvexIsland called on their own give the same sets
+    df = data["do_fracture"]
+    conv = [solid(c["s"]) for c in df["convex"]]
+    cell = np.array(df["piece_cell"], np.int32)
+    n_out = df["n_outside"]
+    assert 0 < n_out < df["n_pieces_in"] and len(conv) > n_out + 10
+    cloud = np.array(df["cloud"], np.float32).reshape(-1, 3)
+    ro, rp = oracle.regroup(conv, cell, n_outside=n_out, partial=True, sphere_points=cloud, origin=np.array(df["origin"], np.float32), radius=df["radius"])
+    want = [sorted(rp[ro[c]:ro[c + 1]].tolist()) for c in range(len(ro) - 1)]
+    assert [sorted(b) for b in df["binds"]] == want
+    assert [sorted(b) for b in df["binds_by_set_functions"]] == want
+    assert len(want[0]) >= n_out and max(len(b) for b in want[1:]) > 1
+    out = df["pieces_out"]
+    flat = [p for b in want for p in b]                      # compounds in order, pieces ascending inside: the order of pieces_out
+    assert len(out) == len(flat) == len(conv)
+    for k, p in enumerate(flat):
+        got_c = solid(out[k]["convex"])
+        if p < n_out:
+            same(got_c, conv[p])                                 # a piece the event skipped comes back as it was
+        elif k % 7 == 0:
+            same(got_c, oracle.refit(conv[p], solid(out[k]["mesh"]), 4))
+    # the three tasks through the reference's signatures (Inc/Surtr.h:270-272): one placed cell, piece 1 outside
+    tk = data["do_fracture"]["tasks"]
+    planes = np.array(tk["cell_planes"], np.float32).reshape(-1, 4)
+    meshes = [solid(t["mesh"]) for t in tk["target"]]; convs = [solid(t["convex"]) for t in tk["target"]]
+    om = np.zeros(len(meshes), np.uint8); om[1] = 1
+    ref = oracle.event(meshes, convs, np.array([0, planes.shape[0]], np.uint32), planes, outside=om, refit=False, render=False)
+    assert len(tk["fractured"]) == ref["frag_ids"].shape[0] > 0
+    ref2 = oracle.event(meshes, convs, np.array([0, planes.shape[0]], np.uint32), planes, outside=om, refit=True, render=True)
+    for k, fr in enumerate(tk["fractured"]):
+        same(solid(fr["mesh"]), fragment(ref, k, "mesh")); same(solid(fr["convex"]), fragment(ref, k, "conv"))
+        same(solid(tk["refitted"][k]["convex"]), fragment(ref2, k, "conv"))
+        a, b = int(ref2["idx_off"][k]), int(ref2["idx_off"][k + 1])
+        assert tk["init"][k]["idx"] == ref2["idx"][a:b].tolist() and tk["init"][k]["nv"] == fragment(ref2, k, "mesh")["pos"].shape[0]
+        assert tk["init"][k]["points"] == fragment(ref2, k, "conv")["pos"].shape[0]
 
 
 # ---- Voronoi cells on the device (row A2) -------------------------------------------------------------------------------
