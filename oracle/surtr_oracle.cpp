@@ -295,10 +295,14 @@ static void clip(Solid& S, const std::vector<Plane>& planes)
             if (S.comp[i] >= 0)
                 for (size_t j = 0; j < S.nb[i].size(); ++j)
                 {
+                    const int e_old = S.nb[i][j];
                     S.nb[i][j] = S.id[S.nb[i][j]];
-                    // a surviving link to a clipped vertex, renumbered through an ID that names no vertex of the compacted
-                    // solid: from here on the reference indexes outside its vertex array (checker bookkeeping, not reference code)
-                    if (live >= 4 && (S.nb[i][j] < 0 || S.nb[i][j] >= live)) g_links_off_the_array.fetch_add(1);
+                    // (checker bookkeeping, not reference code) a surviving link to a CLIPPED vertex is renumbered through that
+                    // vertex's stale ID -- an index of an earlier compaction, or one that was never set and names no vertex of
+                    // the compacted solid, after which the reference indexes outside its vertex array.  Either way what it
+                    // returns is an accident of its memory: the engine flags such a solid instead, and
+                    // the tests ask this counter whether a flag was justified
+                    if (live >= 4 && (S.comp[e_old] < 0 || S.nb[i][j] < 0 || S.nb[i][j] >= live)) g_links_off_the_array.fetch_add(1);
                 }
         int w = 0;
         for (int i = 0; i < n1; ++i)

@@ -23,7 +23,8 @@ for k in sorted(res):
         d = res[k]
         print("%-18s FETCH %10.0f KB  WRITE %10.0f KB  wave cycles %.3g  wait_any %.3g" % (k, d.get("FETCH_SIZE", 0), d.get("WRITE_SIZE", 0), d.get("SQ_WAVE_CYCLES", 0), d.get("SQ_WAIT_ANY", 0)))
 import bench
-clip, prep = res.get("k_clip_pairs", {}), res.get("k_prep_pairs", {})
+dom = "k_clip_pairs_wave" if res.get("k_clip_pairs_wave", {}).get("SQ_WAVE_CYCLES", 0) > res.get("k_clip_pairs", {}).get("SQ_WAVE_CYCLES", 0) else "k_clip_pairs"
+clip, prep = res.get(dom, {}), res.get("k_prep_pairs", {})
 # FETCH_SIZE correction: the guide's x2 holds for 16-B-per-lane streams; this kernel reads 16-B words of the images (x2) and
 # 2..12-B gathers.  With a calibration file the factor measured for its narrowest common access (dword gathers: bytes counted
 # per 64-B line touched) bounds the read side from above; without one the uncorrected figure is a lower bound.
@@ -32,7 +33,7 @@ note = "FETCH_SIZE x2 (the guide's gfx950 correction for wide streaming reads; t
 if calib:
     note += "; calibration on this box: dwordx4 %.2f, dword %.2f, 3 x dword stride 12 %.2f of the true bytes; random dword gathers are counted at %.2f of the 64-B lines they touch" % (
         calib["k16_dwordx4_per_lane"], calib["k4_dword_per_lane"], calib["k12_three_dwords_stride12"], calib["g4_random_dword_vs_64B_lines"])
-rec = {"build_id": bench.kernel_build_id(),
+rec = {"build_id": bench.kernel_build_id(), "kernel": dom,
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, scripts/pmc.sh + scripts/pmc_summary.py) on `python bench.py --steps 2 --warmup 1`, MI355X; per-kernel means in " + os.path.basename(out),
        "k_clip_pairs_FETCH_SIZE_KB": clip.get("FETCH_SIZE"), "k_clip_pairs_WRITE_SIZE_KB": clip.get("WRITE_SIZE"),
        "fetch_correction": factor, "note": note,

@@ -150,7 +150,7 @@ static void api_dump(const char* path, const std::vector<Fragment>& frags, const
         Compound comp;
         for (const auto& fr : frags) if (valid(fr.piece_data.Mesh) && valid(fr.piece_data.Convex)) comp.PieceVec.push_back(fr.piece_data);
         FractureEngine& eng = DefaultEngine();
-        eng.GenerateVoronoi(5, 46354 + 7);
+        const std::vector<VMACH::Polygon3D> cells2 = eng.GenerateVoronoi(5, 46354 + 7);
         const float maxAxis = std::max(ext.x, std::max(ext.y, ext.z));
         FractureArgs args; args.PartialFracture = true;
         args.ImpactPosition = Vector3(cen.x + 0.2f * ext.x, cen.y + 0.1f * ext.y, cen.z); args.ImpactRadius = 0.3f * maxAxis;
@@ -217,9 +217,20 @@ static void api_dump(const char* path, const std::vector<Fragment>& frags, const
         // m_fractureTask / m_refittingTask / m_initCompoundTask through their reference signatures, on one placed cell
         {
             std::vector<Piece*> target;
-            for (size_t i = 0; i < comp.PieceVec.size() && i < 6; ++i) target.push_back(new Piece(comp.PieceVec[i].Convex, comp.PieceVec[i].Mesh));
-            VMACH::Polygon3D cell = cells[0];
-            cell.Scale(ext); cell.Translate(cen);
+            for (size_t i = 0; i < comp.PieceVec.size() && i < 12; ++i) target.push_back(new Piece(comp.PieceVec[i].Convex, comp.PieceVec[i].Mesh));
+            // the cell of the second pattern (placed over the bounding box) that holds the first vertex of the first piece: it cuts
+            // through that piece and its neighbours
+            VMACH::Polygon3D cell;
+            for (const auto& c2 : cells2)
+            {
+                VMACH::Polygon3D c = c2;
+                c.Scale(ext); c.Translate(cen);
+                const Vector3 q = target[0]->Mesh[0].Position;
+                bool inside = true;
+                for (const auto& face : c.FaceVec) if (face.FacePlane.x * q.x + face.FacePlane.y * q.y + face.FacePlane.z * q.z + face.FacePlane.w > 0.f) inside = false;
+                if (inside || cell.FaceVec.empty()) cell = c;
+                if (inside) break;
+            }
             std::set<int> outside; outside.insert(1);
             std::vector<Piece*> got = FractureTask(cell, target, outside);
             fprintf(f, ", \"tasks\": {\"cell_planes\": [");
