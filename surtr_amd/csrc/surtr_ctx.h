@@ -212,6 +212,7 @@ struct surtr_ctx
     ImgArena img{nullptr, 0};
     uint32_t* d_order = nullptr; uint32_t cap_order = 0;
     uint32_t* d_forder = nullptr;    // fragments by size class, 16 x cap_frags
+    bool wave_big = false;           // the large bands through k_clip_pairs_wave_big (one workgroup per CU) instead of k_clip_pairs_big
     uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
     hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both

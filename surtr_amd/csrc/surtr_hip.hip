@@ -884,7 +884,10 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             // k_clip_pairs_big has a few dozen workgroups: on a mesh whose bands outgrow the regular topology as a rule (some
             // 100 000 vertices) it takes the first `big_quota` such pairs and the regular kernel's workgroups do the others on
             // their global scratch (class 13), all of them at once instead of a queue behind 48
-            if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
+            // (big_quota = all ones: the record clipper's whole-CU kernel takes the large bands -- those it can hold, narrow images of
+            // fewer than WC_MAXN vertices; the others are spread over the regular kernel's workgroups as before)
+            if (big_quota == 0xFFFFFFFFu) { if (cls >= 14u && !(fmt == IMG_NARROW && n < WC_MAXN)) cls = 13u; }
+            else if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
             if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
@@ -1144,22 +1147,22 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
 // WC_BAIL -- nothing of the pair has been published, its image is untouched) is clipped right here by the general clipper, on
 // the same LDS bytes: k_prep_pairs puts the pairs it knows to be irregular into the heaviest class, so they come first.
 struct GenLds { Shared sh; LdsTopo L; };
-__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_wave(Pieces P, const float4* __restrict__ planes,
+struct GenLdsBig { Shared sh; LdsTopoBig L; };
+template <class WL, class GL>
+__device__ __attribute__((always_inline)) static inline void clip_pairs_wave_body(unsigned char* lds_raw, uint32_t wg, const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
-                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const ScratchPool& pool, const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
                                                          const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
                                                          uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0)
 {
-    constexpr size_t kBytes = sizeof(WcLds) > sizeof(GenLds) ? sizeof(WcLds) : sizeof(GenLds);
-    __shared__ alignas(16) unsigned char lds_raw[kBytes];
-    WcLds& W = *reinterpret_cast<WcLds*>(lds_raw);
-    GenLds& Gn = *reinterpret_cast<GenLds*>(lds_raw);
+    WL& W = *reinterpret_cast<WL*>(lds_raw);
+    GL& Gn = *reinterpret_cast<GL*>(lds_raw);
     const uint32_t tid = threadIdx.x;
     // this workgroup's scratch slot: used raw by the record clipper (sorted records + positions of a band's originals, positions
     // of the cut points), carved as a Scratch by the general clipper
-    char* slot = pool.base + (size_t)blockIdx.x * pool.per_wg;
-    Scratch S = carve(pool, blockIdx.x);
+    char* slot = pool.base + (size_t)wg * pool.per_wg;
+    Scratch S = carve(pool, wg);
     while (true)
     {
         __syncthreads();
@@ -1201,9 +1204,9 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
             if (tid == 0) for (int q = 0; q < 32; ++q) W.ph[q] = 0ull;
 #endif
             bool fits = false;
-            const WcGlob g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WcLds::kNR, fits);
+            const WcGlob g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WL::kNR, fits);
             if (fits) err = wc_load(W, im, F, g, zmask, ctr, A.cursors + 96);
-            if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WcLds::kNR, o, ctr, A.cursors + 96, walk0);
+            if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WL::kNR, o, ctr, A.cursors + 96, walk0);
             if (err == 0 && o.nLive != 0u) err = wc_park(W, F, rec.img_n, o, g, A, rec, ctr, A.cursors + 96);
 #ifdef SURTR_STAMP
             __syncthreads();
@@ -1224,13 +1227,40 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
         if (err == WC_BAIL)
         {
             __syncthreads();
-            clip_pair_general(Gn.sh, Gn.L, S, pool, blockIdx.x, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
+            clip_pair_general(Gn.sh, Gn.L, S, pool, wg, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
             continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) pair_failed(A, err); }
         if (tid == 0) pairs[p] = rec;
     }
+}
+
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_wave(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0)
+{
+    constexpr size_t kBytes = sizeof(WcLds) > sizeof(GenLds) ? sizeof(WcLds) : sizeof(GenLds);
+    __shared__ alignas(16) unsigned char lds_raw[kBytes];
+    clip_pairs_wave_body<WcLds, GenLds>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, order, horder, cls_hi, cls_lo, qcur, walk0);
+}
+
+// The same with a whole CU's LDS for the record clipper (and the double-size topology for the general one it falls back to): the
+// bands that leave the regular kernels no room (cost classes 15..14, and 13 on meshes where such bands are the rule).  One
+// workgroup per CU; its workgroups use the scratch slots after those of the regular kernel.
+__global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_wave_big(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, uint32_t wg_base, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0)
+{
+    constexpr size_t kBytes = sizeof(WcLdsBig) > sizeof(GenLdsBig) ? sizeof(WcLdsBig) : sizeof(GenLdsBig);
+    __shared__ alignas(16) unsigned char lds_raw[kBytes];
+    clip_pairs_wave_body<WcLdsBig, GenLdsBig>(lds_raw, wg_base + blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, order, nullptr, cls_hi, cls_lo, qcur, walk0);
 }
 
 // -------------------------------------------------------------- k_frag_table
@@ -2709,8 +2739,15 @@ static void budget_workgroups(surtr_ctx* ctx)
         return (uint32_t)std::min<size_t>(hi, std::max<size_t>(lo, n));
     };
     const uint32_t CV = ctx->user_cv ? ctx->user_cv : 2 * ctx->vmax + 4096, CH = ctx->user_ch ? ctx->user_ch : 3 * ctx->hmax + 16384;
-    const uint32_t all = fit(total_b / 4, scratch_bytes_per_wg(std::max(CV, 64u), CH, ctx->vmax), 20u, ctx->hw_wg + ctx->hw_wg_big);
-    ctx->n_wg_big = all >= ctx->hw_wg + ctx->hw_wg_big ? ctx->hw_wg_big : std::min(ctx->hw_wg_big, std::max(4u, all / 8u));
+    const uint32_t all = fit(total_b / 4, scratch_bytes_per_wg(std::max(CV, 64u), CH, ctx->vmax), 20u, ctx->hw_wg + std::max(ctx->hw_wg / 2u, ctx->hw_wg_big));
+    // the large bands go through the record clipper with a whole CU's LDS (k_clip_pairs_wave_big, one workgroup per CU) on
+    // meshes where such bands are the rule; otherwise through k_clip_pairs_big's few dozen workgroups
+    // (measured at 4 096 cells: 100 000-vertex piece 9.5 -> 7.8 ms, 210 000 18.4 -> 14.5 ms; at 500 000 vertices most bands outgrow even
+    // a whole CU's LDS and are better spread over all workgroups' global scratch: 39.7 ms against 61.6)
+    ctx->wave_big = ctx->vmax >= 80000u && ctx->vmax < 300000u;
+    if (const char* e = getenv("SURTR_WAVE_BIG")) ctx->wave_big = atoi(e) != 0;
+    const uint32_t hw_big = ctx->wave_big ? std::max(ctx->hw_wg / 2u, ctx->hw_wg_big) : ctx->hw_wg_big;
+    ctx->n_wg_big = all >= ctx->hw_wg + hw_big ? hw_big : std::min(hw_big, std::max(4u, all / 8u));
     ctx->max_wg = std::min(ctx->hw_wg, all - ctx->n_wg_big);
     size_t HF = (size_t)ctx->hmax + ctx->hmax / 2 + 8192;
     {
@@ -2957,7 +2994,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order);
     PROF_END(6);
-    uint32_t big_quota = 2u * ctx->n_wg_big;
+    uint32_t big_quota = ctx->wave_big ? 0xFFFFFFFFu : 2u * ctx->n_wg_big;
     if (const char* e = getenv("SURTR_BIG_QUOTA")) big_quota = (uint32_t)atoi(e);      // (tests: 0 sends every big band to the regular kernel's global scratch)
     PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
@@ -2980,7 +3017,12 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
     HIPCHK(hipStreamWaitEvent(st3, ctx->ev_prep, 0));
     PROF_BEGIN(8);
-    if (n_pairs)
+    uint32_t walk0 = SURTR_WWALK0;
+    if (const char* e = getenv("SURTR_WWALK0")) { const int v = atoi(e); if (v >= 0 && v <= 64) walk0 = (uint32_t)v; }
+    if (n_pairs && ctx->wave_big)
+        hipLaunchKernelGGL(k_clip_pairs_wave_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
+                           ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, 15, 14, 11u, walk0);
+    else if (n_pairs)
         hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
                            ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
     PROF_END(8);
@@ -2990,8 +3032,6 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // 1.33 -> 1.45 ms; its loader sorts the band, which the general clipper's image copy does not have to)
     bool wave_on = n_pairs > 3u * max_wg;
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
-    uint32_t walk0 = SURTR_WWALK0;
-    if (const char* e = getenv("SURTR_WWALK0")) { const int v = atoi(e); if (v >= 0 && v <= 64) walk0 = (uint32_t)v; }
     PROF_BEGIN_ON(11, st2);
     if (n_pairs && wave_on)
         hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,

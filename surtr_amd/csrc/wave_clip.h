@@ -118,14 +118,14 @@ __device__ __forceinline__ WcRec wc_rec(const unsigned char* B, uint32_t byte_of
 }
 // a 16-byte record at unit `unit` (park: none; loader / global copies use WcW4 directly)
 
-template <uint32_t NR>
+template <uint32_t NR, uint32_t NL = SURTR_WNL>
 struct alignas(16) WcLdsT
 {
-    static constexpr uint32_t kNR = NR;
+    static constexpr uint32_t kNR = NR, kNL = NL;
     alignas(16) unsigned char U[16u * NR];    // cut-point records from the bottom; the plane's stage and lists from the top
     float4 planes[WC_MAXF];
-    uint16_t nlist[2][SURTR_WNL];             // alive cut points (ids) in creation order; the planes alternate between the two
-    uint16_t freel[SURTR_WNL];                // record units of cut points that are gone
+    uint16_t nlist[2][NL];             // alive cut points (ids) in creation order; the planes alternate between the two
+    uint16_t freel[NL];                // record units of cut points that are gone
     uint32_t hist[WC_MAXF + 1], zhist[WC_MAXF + 1];
     uint32_t bst[WC_MAXF + 2];                // first id of bucket k (bucket F: never clipped); bst[F + 1] = n
     uint32_t wcnt[SURTR_NWAVE][WC_MAXF + 2];  // loader: originals per (wave, bucket)
@@ -138,6 +138,12 @@ struct alignas(16) WcLdsT
 #endif
 };
 typedef WcLdsT<SURTR_WR> WcLds;
+// the same with a whole CU's LDS, for the bands that are too large for the regular one (one workgroup per CU)
+#ifndef SURTR_WR_BIG
+#define SURTR_WR_BIG 7424u
+#define SURTR_WNL_BIG 6144u
+#endif
+typedef WcLdsT<SURTR_WR_BIG, SURTR_WNL_BIG> WcLdsBig;
 
 // The reduced Mesh of a pair as k_prep_pairs left it (ImgLayout, surtr_ctx.h).
 struct WcImg
@@ -494,7 +500,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             return make_uint2((uint32_t)__builtin_popcount(km), 0u);
         };
         const uint32_t M = wc_scan_count<2>(W, sc, nC, st2, kfn, [&]() {}).x;
-        if (M > 4095u || keepn + M > SURTR_WNL || nfree + nCn > SURTR_WNL) WC_RET(9);
+        if (M > 4095u || keepn + M > LT::kNL || nfree + nCn > LT::kNL) WC_RET(9);
         const uint32_t bmw = (M + 31u) / 32u;
         if (4u * rtop + 3u * M + 2u * bmw + 2u * nC + 64u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
         const uint32_t src = carve(M), srcid = carve(M), wst = carve(M), nd = carve(2u * nC), bm = carve(2u * bmw);

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_event_equal
+from helpers import assert_event_equal, fragment
 from surtr_amd import meshgen, scenes
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -115,3 +115,50 @@ def test_record_clipper_small_blocks_and_walk_thresholds(gpu_engine, oracle, mon
     assert c.status == 0
     assert_event_equal(got, ref)
     assert int(qs[88]) > 0
+
+
+def test_record_clipper_big_bands_kernel_emulation(emul_lib_path, oracle, monkeypatch):
+    """k_clip_pairs_wave_big (the record clipper with a whole CU's LDS, for the bands that leave the regular topology no room:
+    cost classes 15..14) forced on, in the emulation build whose LDS topology is tiny -- every band is a "large" one there."""
+    from surtr_amd import engine
+    monkeypatch.setenv("SURTR_WAVE", "1")
+    monkeypatch.setenv("SURTR_WAVE_BIG", "1")
+    engine._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), "libsurtr_emul_mid.so"))
+    try:
+        sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+        c, got, ref, qs = _event(engine, oracle, sc, 128)
+    finally:
+        engine._use_library_for_tests(None)
+    assert c.status == 0
+    assert_event_equal(got, ref)
+    assert int(qs[88]) > 5 and int(qs[16 + 14]) + int(qs[16 + 15]) > 50, (int(qs[88]), qs[16:32].tolist())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("big", ["1", "0"])
+def test_record_clipper_big_bands_kernel_gpu(gpu_engine, oracle, monkeypatch, big):
+    """A 100 000-vertex torus x 4 096 cells (bands beyond the regular LDS topology are the rule): sampled cells against the
+    oracle with the large bands through k_clip_pairs_wave_big / through k_clip_pairs_big."""
+    monkeypatch.setenv("SURTR_WAVE_BIG", big)
+    v, t = meshgen.bumpy_torus(500, 200)
+    eng = gpu_engine.Engine(0)
+    try:
+        sc = scenes.make_scene(v, t, 4096, eng=eng)
+        sc["mesh"] = eng.neighbors_from_mesh(v, t)[0]
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.place_cells(sc["scale"], sc["translate"])
+        c = eng.fracture_event(0, 4096)
+        assert c.status == 0 and c.n_frag > 2500
+        qs = eng.queue_stats()
+        assert (int(qs[88]) > 1000) if big == "1" else True
+        whole = eng.download()
+        planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+        ids = whole["frag_ids"]
+        for cell in range(0, 4096, 256):
+            ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, refit=True, render=True, threads=1, cell_begin=cell, cell_end=cell + 1)
+            ks = np.nonzero(ids[:, 0] == cell)[0]
+            assert ks.shape[0] == ref["frag_ids"].shape[0]
+            for j, k in enumerate(ks):
+                a, b = fragment(whole, int(k), "mesh"), fragment(ref, j, "mesh")
+                assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]) and np.array_equal(a["pos"], b["pos"])
+    finally:
+        eng.close()
