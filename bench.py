@@ -2,7 +2,10 @@
 """bench.py -- fragments/sec + ms/fracture-event on BASELINE.json's configs[3]:
 100k-triangle synthetic mesh (bumpy torus, 50 000 v / 100 000 tri) x 4096 Voronoi cells.
 
-A "step" is one fracture event per GPU on device-resident inputs: cell placement (A3), clip of Convex and
+A "step" is one fracture event per GPU on device-resident inputs (by default three independent events are in flight per GPU --
+three engines on three streams take the steps in turn, so that the under-filled tails of one event's kernels run beside the next
+event's; `--in-flight 1` runs them one after the other, and the JSON line carries that single-event latency too as
+`ms_per_fracture_event`): cell placement (A3), clip of Convex and
 Mesh against every cell + island split (A7, A8, A11), refit (A12), face extraction + ear clipping
 (A9, A10), pack of the fragment blob, and -- for N > 1 -- one all-gather of the blobs over RCCL, issued on
 RCCL's stream so that it runs beside the kernels of the next event (two blob buffers); the timed region ends
@@ -68,7 +71,7 @@ def main():
     ap.add_argument("--cells", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
-    ap.add_argument("--in-flight", type=int, default=1, help="independent events in flight per GPU: E engines (contexts) on E streams take the steps in "
+    ap.add_argument("--in-flight", type=int, default=3, help="independent events in flight per GPU: E engines (contexts) on E streams take the steps in "
                                                            "turn, so that the under-filled tail of one event's kernels runs beside the next event's")
     ap.add_argument("--equal-blocks", action="store_true", help="strong sharding in equal-sized cell blocks instead of cost-balanced ones")
     ap.add_argument("--force-dist", action="store_true", help="rehearsal: take the N > 1 code path (process group, all-gather) with one rank")
@@ -234,6 +237,18 @@ def main():
         total_frag += c.n_frag
         parts.append((c, fr))
 
+    # latency of ONE event with nothing else on the GPU (engine 0 alone, same work): what `ms_per_step` would be with --in-flight 1
+    lat = []
+    for _ in range(max(3, min(args.steps, 10))):
+        fence()
+        t0 = time.perf_counter()
+        eng.place_cells(sc["scale"], sc["translate"])
+        eng.fracture_event_async(cb, ce, flags=flags)
+        eng.pack_dev(blob.data_ptr(), cap)
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    single_event_ms = float(np.median(lat))
+
     # dominant-kernel timing with HIP events on the work stream (separate short loop, same work)
     eng.set_profiling(True)
     clip_ms = []
@@ -300,7 +315,7 @@ def main():
                        "events_in_flight": max(1, args.in_flight),
                        "parallelism": ("%d ranks x one %d-cell event each, one all-gather" % (world, sc["n_cells"])) if args.scaling == "weak"
                                       else ("one event, cells sharded x%d in contiguous %s blocks, one all-gather" % (world, "equal-sized" if args.equal_blocks else "cost-balanced") if world > 1 else "one GPU")},
-            "ms_per_fracture_event": ms_per_step,
+            "ms_per_fracture_event": single_event_ms,
             "kernel_ms": {k: float(np.mean(v)) for k, v in all_ms.items()},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,

@@ -486,14 +486,13 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                 const bool kept = ee[q] < WC_MAXN ? ee[q] >= b1 : (ee[q] < WC_SENT && (tl[q] & 0xFFu) > k);
                 if (kept) km |= 1u << q;
             }
-            // a ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354)
-            if (km & (km - 1u))
+            // A ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354).  The rings of
+            // the originals list no vertex twice (the piece has none: Pieces::mdup, checked by the caller; a patch puts the cut
+            // point of ONE edge into ONE entry), so only a cut point's ring can: [Z, Z, kept] of a cap of two vertices, or
+            // [pred, succ, kept] with kept among them.
+            if (id >= WC_MAXN && (km & (km - 1u)))
             {
-#pragma unroll
-                for (uint32_t q = 1; q < 7u; ++q)
-#pragma unroll
-                    for (uint32_t q2 = 0; q2 < q; ++q2)
-                        if (((km >> q) & 1u) && ((km >> q2) & 1u) && ee[q] == ee[q2]) bad = true;
+                if ((((km & 3u) == 3u) && ee[0] == ee[1]) || (((km & 5u) == 5u) && ee[0] == ee[2]) || (((km & 6u) == 6u) && ee[1] == ee[2])) bad = true;
             }
             wc_st8(B, ckm8 + i, km);
             aux = km | (id << 8) | (((r.tail() >> 8) & 7u) << 24);
