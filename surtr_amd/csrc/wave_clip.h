@@ -544,7 +544,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         auto walk = [&](uint32_t& cv, uint32_t& pcv, uint32_t& p, WcRec& rc, uint32_t& steps, const uint32_t limit, const bool jump) -> uint32_t {
             while (true)
             {
-                if (jump && p == 0u)
+                if (jump && p == 0u && pcv >= nCo)
                 {
                     // a run of clipped vertices each entered through its slot 1 and left through its slot 0: the pointer
                     // jumping below collapsed it (clip_core.h does the same for its resumed walks)
@@ -596,13 +596,14 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             // nd[i] = (where the walk that stands on clipped vertex i, about to take its slot 0, gets to along its run | steps):
             // it moves on to e0 whenever slot 0 holds no kept vertex, and is there about to take slot 0 again when it arrives
             // through e0's slot 1
-            for (uint32_t i = tid; i < nC; i += G)
+            // (only the cut points get an entry: the runs are runs of cap vertices; a walk that stands on an original steps on)
+            for (uint32_t i = nCo + tid; i < nC; i += G)
             {
                 const uint32_t c = clipped_id(i);
                 const WcRec r = rec_of(c);
                 const uint32_t e0 = r.e(0u);
                 uint32_t nx = i, d = 0;
-                if (!(wc_ld8(B, ckm8 + i) & 1u) && e0 < WC_SENT && (e0 >= WC_MAXN || (e0 >= b0 && e0 < b1)))
+                if (!(wc_ld8(B, ckm8 + i) & 1u) && e0 >= WC_MAXN && e0 < WC_SENT)
                 {
                     const WcRec r0 = rec_of(e0);
                     const uint32_t t0 = r0.tail();
@@ -614,7 +615,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             for (uint32_t round = 0; round < 12u; ++round)
             {
                 bool ch = false;
-                for (uint32_t i = tid; i < nC; i += G)
+                for (uint32_t i = nCo + tid; i < nC; i += G)
                 {
                     // (two levels per round: whatever value a lane reads is a vertex further down the same run, with its distance)
                     const uint32_t a = wc_ld32(B, nd + 2u * i), j1 = a & 0xFFFFu;
