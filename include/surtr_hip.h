@@ -110,6 +110,10 @@ int surtr_set_arena(surtr_ctx* ctx, uint64_t verts, uint64_t nbrs, uint64_t idx)
  * two internal streams); -1 where not run. */
 int surtr_set_profiling(surtr_ctx* ctx, int on);
 int surtr_kernel_times(surtr_ctx* ctx, float ms[16]);
+/* The durations of the Mesh clip kernel (slot[k] = 0: k_clip_pairs, 11: k_clip_pairs_wave) over the last *n <= 16 events since
+ * surtr_set_profiling(ctx, 1), oldest first, without a synchronisation between the events: what a caller that keeps several
+ * events in flight (several contexts on several streams) averages for the kernel's launch duration under those conditions. */
+int surtr_kernel_history(surtr_ctx* ctx, float ms[16], int slot[16], uint32_t* n);
 /* Diagnostic: the device-side counters of the last event (synchronises the stream).  out[0..3] arena use (vertices, ring
  * entries, indices, islands), [5] status, [16+c] pairs of cost class c handed to k_clip_pairs(_big), [32+c] fragments of size
  * class c, [48+c] pairs of pre-pass class c, [64+c] pairs of class c handed to k_clip_pairs_half, [64] pairs that outgrew

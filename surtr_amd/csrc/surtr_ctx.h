@@ -263,12 +263,18 @@ struct surtr_ctx
     void* d_blob = nullptr; size_t blob_cap = 0;
     // per-kernel timing with HIP events on the work stream (surtr_set_profiling)
     bool profiling = false;
+    // history of the Mesh clip kernel (slot 0: k_clip_pairs, slot 11: k_clip_pairs_wave) over the last events, read without a
+    // synchronisation in between (surtr_kernel_history): what a caller with several events in flight averages over
+    hipEvent_t hev[16][2] = {}; uint32_t hcount = 0; int hslot[16] = {};
     hipEvent_t ev[32] = {};     // begin/end per kernel slot 0..15
     bool ev_valid[16] = {};
 };
 
 #define PROF_BEGIN_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i)], strm); } } while (0)
 #define PROF_END_ON(i, strm) do { if (ctx->profiling) { (void)hipEventRecord(ctx->ev[2 * (i) + 1], strm); ctx->ev_valid[i] = true; } } while (0)
+// the same into the history ring (only where a kernel was really launched)
+#define PROF_HIST_BEGIN(i, strm) do { if (ctx->profiling && ctx->hev[0][0]) { (void)hipEventRecord(ctx->hev[ctx->hcount % 16u][0], strm); } } while (0)
+#define PROF_HIST_END(i, strm) do { if (ctx->profiling && ctx->hev[0][0]) { (void)hipEventRecord(ctx->hev[ctx->hcount % 16u][1], strm); ctx->hslot[ctx->hcount % 16u] = (i); ++ctx->hcount; } } while (0)
 #define PROF_BEGIN(i) PROF_BEGIN_ON(i, st)
 #define PROF_END(i) PROF_END_ON(i, st)
 

@@ -2611,6 +2611,7 @@ void surtr_destroy(surtr_ctx* ctx)
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     for (int i = 0; i < 32; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 16; ++i) for (int q = 0; q < 2; ++q) if (ctx->hev[i][q]) (void)hipEventDestroy(ctx->hev[i][q]);
     free_dev(ctx->arena.pos); free_dev(ctx->arena.loff); free_dev(ctx->arena.llen); free_dev(ctx->arena.nbr);
     free_dev(ctx->arena.idx); free_dev(ctx->arena.isl); free_dev(ctx->arena.cursors);
     free_dev(ctx->d_pairs); free_dev(ctx->d_frags); free_dev(ctx->d_frag_status); free_dev(ctx->d_scanblk); free_dev(ctx->d_counts);
@@ -3033,14 +3034,18 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     bool wave_on = n_pairs > 3u * max_wg;
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
     PROF_BEGIN_ON(11, st2);
+    if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st2);
     if (n_pairs && wave_on)
         hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u, walk0);
+    if (n_pairs && wave_on) PROF_HIST_END(11, st2);
     PROF_END_ON(11, st2);
     PROF_BEGIN_ON(0, st2);
+    if (n_pairs && !wave_on) PROF_HIST_BEGIN(0, st2);
     if (n_pairs && !wave_on)
         hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
+    if (n_pairs && !wave_on) PROF_HIST_END(0, st2);
     PROF_END_ON(0, st2);
     PROF_BEGIN_ON(9, st3);
     if (n_pairs && ctx->half_on)
@@ -3492,6 +3497,9 @@ int surtr_set_profiling(surtr_ctx* ctx, int on)
     (void)hipSetDevice(ctx->device);
     if (on && !ctx->ev[0])
         for (int i = 0; i < 32; ++i) HIPCHK(hipEventCreate(&ctx->ev[i]));
+    if (on && !ctx->hev[0][0])
+        for (int i = 0; i < 16; ++i) { HIPCHK(hipEventCreate(&ctx->hev[i][0])); HIPCHK(hipEventCreate(&ctx->hev[i][1])); }
+    ctx->hcount = 0;
     ctx->profiling = on != 0;
     return SURTR_OK;
 }
@@ -3504,6 +3512,23 @@ int surtr_kernel_times(surtr_ctx* ctx, float ms[16])
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 16; ++i)
         if (ctx->ev_valid[i]) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->ev[2 * i], ctx->ev[2 * i + 1]) == hipSuccess) ms[i] = t; }
+    return SURTR_OK;
+}
+
+int surtr_kernel_history(surtr_ctx* ctx, float ms[16], int slot[16], uint32_t* n)
+{
+    if (!ctx || !ms || !slot || !n) return SURTR_E_INVALID;
+    (void)hipSetDevice(ctx->device);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const uint32_t have = ctx->hcount < 16u ? ctx->hcount : 16u;
+    for (uint32_t k = 0; k < have; ++k)
+    {
+        const uint32_t at = (ctx->hcount - have + k) % 16u;      // oldest first
+        float t = -1.f;
+        if (hipEventElapsedTime(&t, ctx->hev[at][0], ctx->hev[at][1]) != hipSuccess) t = -1.f;
+        ms[k] = t; slot[k] = ctx->hslot[at];
+    }
+    *n = have;
     return SURTR_OK;
 }
 

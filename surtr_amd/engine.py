@@ -141,6 +141,12 @@ class Engine:
         names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry", "clip_pairs_wave")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
+    def kernel_history(self):
+        """Durations (ms) of the Mesh clip kernel over the last events, oldest first (surtr_kernel_history)."""
+        ms = (ctypes.c_float * 16)(); slot = (ctypes.c_int * 16)(); n = ctypes.c_uint32(0)
+        self._ck(lib().surtr_kernel_history(self._h, ms, slot, ctypes.byref(n)))
+        return [float(ms[i]) for i in range(n.value)]
+
     def pair_status(self, n_pairs):
         """Status per pair of the last event (include/surtr_hip.h: surtr_pair_status)."""
         out = np.zeros(n_pairs, dtype=np.uint32)
