@@ -6,6 +6,11 @@
 // bench.py.  Nothing under surtr_amd/ may include, link or call this file:
 // only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
 //
+// UNDEFINED BEHAVIOUR OF THE REFERENCE: where ClipPolyhedron's compaction stores a link that names no vertex (an ID of -1 or
+// past the new size, Src/Poly.cpp:484-493) the reference goes on to index outside its arrays.  There is nothing to restate
+// there: clip() counts the link (orc_links_off_the_array), stops with an empty solid, and the tests accept the engine's flag
+// for that pair or fragment instead of comparing results.
+//
 // PINNING STATUS: the reference ships no tests, fixtures or golden vectors
 //  and cannot be built in this image (every translation
 // unit includes Inc/pch.h -> Windows.h, d3d12.h, DirectXMath.h, none present;
@@ -289,6 +294,7 @@ static void clip(Solid& S, const std::vector<Plane>& planes)
         // -- compaction, :464-495
         bb.reset();
         int live = 0;
+        bool off_the_array = false;
         for (int i = 0; i < n1; ++i)
             if (S.comp[i] >= 0) { S.id[i] = live++; bb.grow(S.pos[i]); }
         for (int i = 0; i < n1; ++i)
@@ -303,6 +309,7 @@ static void clip(Solid& S, const std::vector<Plane>& planes)
                     // returns is an accident of its memory: the engine flags such a solid instead, and
                     // the tests ask this counter whether a flag was justified
                     if (live >= 4 && (S.comp[e_old] < 0 || S.nb[i][j] < 0 || S.nb[i][j] >= live)) g_links_off_the_array.fetch_add(1);
+                    if (live >= 4 && (S.nb[i][j] < 0 || S.nb[i][j] >= live)) off_the_array = true;
                 }
         int w = 0;
         for (int i = 0; i < n1; ++i)
@@ -316,6 +323,11 @@ static void clip(Solid& S, const std::vector<Plane>& planes)
         }
         S.pos.resize(w); S.nb.resize(w); S.comp.resize(w); S.id.resize(w);
         if (S.size() < 4) S.clear();                                   // :497-499
+        // (checker behaviour, not reference code) a stored link that names no vertex: from here on the reference indexes outside
+        // its vertex array (comp[-1] at :336 of the next plane, or whoever walks the solid next) and what it returns, if it
+        // returns, depends on its heap.  There is nothing to restate: the checker stops with an empty solid, and the counter
+        // above tells the tests why (the engine flags such a pair or fragment)
+        if (off_the_array) { S.clear(); return; }
     }
 }
 

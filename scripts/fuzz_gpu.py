@@ -59,7 +59,8 @@ def main():
                                 conv_pos=sc["convex"]["pos"], conv_off=sc["convex"]["off"], conv_nbr=sc["convex"]["nbr"], face_off=sc["face_off"], planes=planes, flags=flags)
             code = ("import sys, numpy as np; sys.path.insert(0, %r); from oracle import oracle as O; d = np.load(%r); "
                     "O.event([dict(pos=d['mesh_pos'], off=d['mesh_off'], nbr=d['mesh_nbr'])], [dict(pos=d['conv_pos'], off=d['conv_off'], nbr=d['conv_nbr'])], "
-                    "d['face_off'], d['planes'], refit=bool(int(d['flags']) & 1), render=bool(int(d['flags']) & 2), threads=1)") % (ROOT, path)
+                    "d['face_off'], d['planes'], refit=bool(int(d['flags']) & 1), render=bool(int(d['flags']) & 2), threads=1); "
+                    "sys.exit(3 if O.links_off_the_array() > 0 else 0)") % (ROOT, path)      # (a link off the vertex array: the restatement stops there)
             rc = subprocess.call([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             if rc == 0:
                 bad += 1

@@ -570,21 +570,60 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         // every new vertex must be the successor of exactly one other: all M walks end on one of the M new vertices, so it is
         // enough that no two end on the same one (a bit per new vertex).  (A cap of two vertices gives rings [Z, Z, kept], as in
         // the reference; a later plane that meets such a ring at a clipped vertex finds it in the doubled-neighbour test above.)
+        // The walk of new vertex t that ends on new vertex `end` links the two: X is the predecessor of Z, Z the successor of X.
         auto arrive = [&](uint32_t t, uint32_t end) {
-            wc_st16(B, wst + t, 0x8000u | end);
+            wc_st16(B, wst + t, 0xFFFFu);
             uint32_t* word = (uint32_t*)(void*)(B + 2u * (size_t)(bm + 2u * (end >> 5)));
             if (end == t || (atomicOr(word, 1u << (end & 31u)) & (1u << (end & 31u)))) { SURTR_DBG("  wc walk: ends on itself / second arrival t=%u end=%u k=%u\n", t, end, k); fail = true; }
+            const uint32_t X = xof(t), Z = xof(end);
+            wc_st16(B, 4u * (Z - WC_MAXN), X);
+            wc_st16(B, 4u * (X - WC_MAXN) + 1u, Z);
         };
+        // ---- the new vertices: first steps of the walk, position, first clipping plane, record [pred, succ, kept end], back-link
+        //      of the kept end -- one pass: the positions of the two ends and the record of the kept end come from global memory /
+        //      L2 and are in flight while the walk takes its steps in LDS.  (Nothing but the two links depends on where the walk
+        //      ends; nothing here reads what another thread writes here: the records of new vertices and of kept vertices are
+        //      not on any walk's way.) ----
         bool paused = false;
+        uint32_t myz0 = 0, myz1 = 0;
+        uint16_t* nnow = W.nlist[cur];
         for (uint32_t t = tid; t < M; t += G)
         {
             const uint32_t s = wc_ld16(B, src + t);
-            uint32_t pcv = s & 0xFFFu, cv = wc_ld16(B, srcid + t);
-            const uint32_t j = s >> 12;
+            const uint32_t v = wc_ld16(B, srcid + t), j = s >> 12;
+            uint32_t pcv = s & 0xFFFu, cv = v;
             WcRec rc = rec_of(cv);
+            const uint32_t u = rc.e(j);
+            const float4 pa = v < WC_MAXN ? g.gpos[v] : g.cpos[v - WC_MAXN];
+            const float4 pb = u < WC_MAXN ? g.gpos[u] : g.cpos[u - WC_MAXN];
+            // the kept end: an original lives in global memory, a cut point in LDS
+            WcW4 wru = WcW4{0u, 0u, 0u, 0u};
+            if (u < WC_MAXN) wru = g.grec[u];
             const uint32_t lv = (rc.tail() >> 12) & 7u;
             uint32_t p = j ? j - 1u : lv - 1u, steps = 0;
             const uint32_t end = walk(cv, pcv, p, rc, steps, walk0, false);
+            const uint32_t X = xof(t), ux = X - WC_MAXN;
+            // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
+            const float sa = plane_dist(pl, pa.x, pa.y, pa.z), sb = plane_dist(pl, pb.x, pb.y, pb.z);
+            const float inv = 1.f / (sb - sa);
+            const float nx = (pa.x * sb - pb.x * sa) * inv, ny = (pa.y * sb - pb.y * sa) * inv, nz = (pa.z * sb - pb.z * sa) * inv;
+            g.cpos[ux] = make_float4(nx, ny, nz, 0.f);
+            uint32_t f = SURTR_NEVER;
+            for (uint32_t q = k + 1u; q < F; ++q)
+            {
+                const int cq = side_of(plane_dist(W.planes[q], nx, ny, nz));
+                if (cq < 0) { f = q; break; }
+                if (cq == 0) { if (q < 32u) myz0 |= 1u << q; else myz1 |= 1u << (q - 32u); }
+            }
+            // the record but for its slots 0 and 1, which the walks that end on X and start from X write
+            wc_st32(B, 4u * ux + 2u, u | ((f | (3u << 8)) << 16));
+            nnow[keepn + t] = (uint16_t)X;
+            // the kept end now links X instead of v (:350-354: first occurrence)
+            const WcRec ru = u < WC_MAXN ? WcRec{wru.a, wru.b, wru.c, wru.d} : wc_rec(B, 8u * (u - WC_MAXN), true);
+            const uint32_t tu = ru.tail(), qu = ru.find(v, (tu >> 8) & 7u);
+            if ((tu & 0x8000u) || qu >= ((tu >> 8) & 7u)) { SURTR_DBG("  wc patch: kept end does not link the clipped vertex k=%u\n", k); fail = true; }
+            else if (u < WC_MAXN) { const uint16_t xv = (uint16_t)X; __builtin_memcpy(GB + 16u * (size_t)u + 2u * qu, &xv, 2); }
+            else wc_st16(B, 4u * (u - WC_MAXN) + qu, X);
             if (end != WC_NONE) arrive(t, end);
             else { wc_st16(B, wst + t, pcv | (p << 12)); paused = true; }
         }
@@ -632,7 +671,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             for (uint32_t t = tid; t < M; t += G)
             {
                 const uint32_t ws = wc_ld16(B, wst + t);
-                if (ws & 0x8000u) continue;
+                if (ws == 0xFFFFu) continue;
                 uint32_t pcv = ws & 0xFFFu, cv = clipped_id(pcv), p = ws >> 12, steps = walk0;
                 WcRec rc = rec_of(cv);
                 const uint32_t end = walk(cv, pcv, p, rc, steps, 0xFFFFFFFFu, true);
@@ -643,48 +682,6 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
 #endif
             }
             WSTAMP(7);
-        }
-        // ---- the new vertices: position, first clipping plane, record [pred, succ, kept end], back-link of the kept end.
-        //      (Nothing here reads what another thread's walk left: no barrier between the walks and this.) ----
-        uint32_t myz0 = 0, myz1 = 0;
-        uint16_t* nnow = W.nlist[cur];
-        for (uint32_t t = tid; t < M; t += G)
-        {
-            const uint32_t ws = wc_ld16(B, wst + t);
-            if (!(ws & 0x8000u)) continue;            // (a walk that failed: the pair is given up below)
-            const uint32_t end = ws & 0xFFFu;
-            const uint32_t v = wc_ld16(B, srcid + t), j = wc_ld16(B, src + t) >> 12;
-            const uint32_t X = xof(t), Z = xof(end);
-            const WcRec r = rec_of(v);
-            const uint32_t u = r.e(j);
-            const float4 pa = v < WC_MAXN ? g.gpos[v] : g.cpos[v - WC_MAXN];
-            const float4 pb = u < WC_MAXN ? g.gpos[u] : g.cpos[u - WC_MAXN];
-            // the kept end: an original lives in global memory, a cut point in LDS
-            WcRec ru;
-            if (u < WC_MAXN) { const WcW4 wr = g.grec[u]; ru = WcRec{wr.a, wr.b, wr.c, wr.d}; } else ru = wc_rec(B, 8u * (u - WC_MAXN), true);
-            const uint32_t ux = X - WC_MAXN, uz = Z - WC_MAXN;
-            wc_st16(B, 4u * uz, X);                                                // X is the predecessor of Z
-            // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
-            const float sa = plane_dist(pl, pa.x, pa.y, pa.z), sb = plane_dist(pl, pb.x, pb.y, pb.z);
-            const float inv = 1.f / (sb - sa);
-            const float nx = (pa.x * sb - pb.x * sa) * inv, ny = (pa.y * sb - pb.y * sa) * inv, nz = (pa.z * sb - pb.z * sa) * inv;
-            g.cpos[ux] = make_float4(nx, ny, nz, 0.f);
-            uint32_t f = SURTR_NEVER;
-            for (uint32_t q = k + 1u; q < F; ++q)
-            {
-                const int cq = side_of(plane_dist(W.planes[q], nx, ny, nz));
-                if (cq < 0) { f = q; break; }
-                if (cq == 0) { if (q < 32u) myz0 |= 1u << q; else myz1 |= 1u << (q - 32u); }
-            }
-            // the record but for its slot 0, which the walk that ends on X writes
-            wc_st16(B, 4u * ux + 1u, Z);
-            wc_st32(B, 4u * ux + 2u, u | ((f | (3u << 8)) << 16));
-            nnow[keepn + t] = (uint16_t)X;
-            // the kept end now links X instead of v (:350-354: first occurrence)
-            const uint32_t tu = ru.tail(), qu = ru.find(v, (tu >> 8) & 7u);
-            if ((tu & 0x8000u) || qu >= ((tu >> 8) & 7u)) { SURTR_DBG("  wc patch: kept end does not link the clipped vertex k=%u\n", k); fail = true; continue; }
-            if (u < WC_MAXN) { const uint16_t xv = (uint16_t)X; __builtin_memcpy(GB + 16u * (size_t)u + 2u * qu, &xv, 2); }
-            else wc_st16(B, 4u * (u - WC_MAXN) + qu, X);
         }
         if (myz0) atomicOr(&W.zm[0], myz0);
         if (myz1) atomicOr(&W.zm[1], myz1);
