@@ -15,9 +15,10 @@
 //             into LDS when their plane comes ("stage"): no selection scan, and only what a plane works on is in LDS.  Whether
 //             an original neighbour is kept is a comparison of its id with the bucket boundary: no lookup.  The back-link of a
 //             kept original is patched where it lives (one 16-byte read, one 2-byte write, beside the position gathers).
-//   nlist     the cut points that are still alive (records in LDS), in creation order: one ordered filter per plane gives
-//             the clipped cut points in the reference's order (Src/Poly.cpp:333-357 numbers new vertices by (clipped vertex,
-//             slot); the compaction :464-495 keeps creation order) and, at the end, the output order.
+//   nlist     the cut points that are still alive (records in LDS), in creation order.  ONE ordered scan per plane over
+//             (the plane's originals, then this list) gives the clipped vertices in the reference's order, the numbers of
+//             their new vertices (Src/Poly.cpp:333-357 numbers new vertices by (clipped vertex, slot)) and the next plane's
+//             list (the compaction :464-495 keeps creation order); at the end the list is the output order.
 //   no slots  ids are record addresses and order is carried by bucket / nlist positions, so nothing is ever renumbered,
 //             squeezed or tombstoned; the records of clipped cut points go to a free list.
 //
@@ -406,7 +407,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
     const uint32_t tid = threadIdx.x, G = group_size();
     unsigned char* B = W.U;
     unsigned char* GB = (unsigned char*)g.grec;               // (16-bit patches of original records)
-    uint32_t rtop = 0, nl = 0, nLive = n, cur = 0, nfree = 0;  // cut-point records in use from the bottom; free-list length
+    uint32_t rtop = 0, nl = 0, nLive = n, cur = 0, nfree = 0, fhead = 0;  // cut-point records in use from the bottom; free list (a ring in W.freel): length, head
     uint32_t ac = ctr.ac, sc = ctr.sc;
     out.nl = 0; out.nLive = 0; out.rtop = 0; out.cur = 0;
     WSTAMP_DECL;
@@ -419,58 +420,42 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         const uint32_t nCo = b1 - b0;
         uint32_t ltop = 8u * LT::kNR;                     // stage and lists are carved downwards from the top (16-bit word index, 16-byte steps)
         auto carve = [&](uint32_t cnt16) -> uint32_t { ltop -= (cnt16 + 7u) & ~7u; return ltop; };
-        if (4u * rtop + 8u * nCo + nl + 64u > ltop) WC_RET(4);
-        // ---- stage: this plane's originals into LDS (their records are final: every patch of an earlier plane is in).  The
-        //      first two records of every thread are in flight while the cut points are filtered. ----
+        // ---- the plane's ITEMS: its originals [0, nCo) -- all clipped --, then the alive cut points in creation order (clipped
+        //      when their first clipping plane is this one).  One ordered scan over the items gives the clipped list in the
+        //      reference's order (a clipped vertex is known by its item index from here on: tails, kept masks, first new vertex),
+        //      the number of the first new vertex of every clipped vertex (Src/Poly.cpp:333-357 numbers them by (clipped vertex,
+        //      slot)), and the place of every kept cut point in the next plane's list. ----
+        const uint32_t NI = nCo + nl;
+        if (NI > 4095u) WC_RET(6);
+        if (4u * rtop + 8u * nCo + NI + (NI + 1u) / 2u + 64u > ltop) WC_RET(4);
+        // stage: this plane's originals in LDS (their records are final: every patch of an earlier plane is in)
         const uint32_t stage = carve(8u * nCo) / 8u;      // first unit of the stage
         auto stage_put = [&](uint32_t i, const WcW4& wr) { __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16); };
-        WcW4 sg0 = WcW4{0u, 0u, 0u, 0u}, sg1 = WcW4{0u, 0u, 0u, 0u};
-        if (tid < nCo) sg0 = g.grec[b0 + tid];
-        if (tid + G < nCo) sg1 = g.grec[b0 + tid + G];
         // where the record of a vertex that is in LDS sits: a cut point (pool, 8-byte units from the bottom) or an original of this
         // plane (stage); t16_of: 16-bit word index of its tail
         auto off_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 8u * (e - WC_MAXN) : 16u * (stage + (e - b0)); };
         auto t16_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 4u * (e - WC_MAXN) + 3u : 8u * (stage + (e - b0)) + 7u; };
         auto rec_of = [&](uint32_t e) -> WcRec { return wc_rec(B, off_of(e), e >= WC_MAXN); };
-        // ---- the clipped cut points (first clipping plane == k), in creation order; the others move to the other nlist, in order ----
-        const uint32_t cnew = carve(nl);
         const uint16_t* nin = W.nlist[cur]; uint16_t* nout = W.nlist[cur ^ 1u];
-        WcScanState<2> st1;
-        auto nfl = [&](uint32_t i, uint32_t& e) -> uint2 { e = nin[i]; const bool c = (wc_ld16(B, 4u * (e - WC_MAXN) + 3u) & 0xFFu) == k; return make_uint2(c ? 1u : 0u, c ? 0u : 1u); };
-        const uint2 nt = wc_scan_count<2>(W, sc, nl, st1, nfl, [&]() {
-            if (tid < nCo) stage_put(tid, sg0);
-            if (tid + G < nCo) stage_put(tid + G, sg1);
-            for (uint32_t i = tid + 2u * G; i < nCo; i += G) stage_put(i, g.grec[b0 + i]);
-        });
-        const uint32_t nCn = nt.x, keepn = nt.y;
-        wc_scan_place<2>(nl, st1, nfl, [&](uint32_t, uint32_t xc, uint32_t xk, uint2 c, uint32_t e) { if (c.x) wc_st16(B, cnew + xc, e); else nout[xk] = (uint16_t)e; });
-        cur ^= 1u;
-        __syncthreads();
-        WSTAMP(2);
-        const uint32_t nC = nCo + nCn;
-        const uint32_t dropAlive = SURTR_UNIFORM(W.hist[k]);
-        const uint32_t dropKept = dropAlive - SURTR_UNIFORM(W.zhist[k]);      // dropped vertices strictly on the kept side
-        if (nLive <= nC && dropKept == 0u)
-        {
-            if (nC == 0u) WC_RET(5);                 // every vertex in the plane: the bounding-box rule (:296-299) of the general clipper
-            nLive = 0; break;                             // "below": everything goes (:322-327)
-        }
-        if (nC == 0u)
-        {
-            nl = keepn;
-            if (nLive + dropAlive < 4u) { nLive = 0; break; }      // (:497-499)
-            continue;
-        }
-        if (nC > 4095u) WC_RET(6);
-        // ---- kept neighbours of every clipped vertex (bit j = ring slot j), number of its first new vertex ----
-        if (4u * rtop + 2u * nC + 32u > ltop) WC_RET(7);
-        const uint32_t cbase = carve(nC), ckm8 = 2u * carve((nC + 1u) / 2u);      // ckm8: byte index
-        auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : wc_ld16(B, cnew + (i - nCo)); };
+        auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : (uint32_t)nin[i - nCo]; };
+        const uint32_t cbase = carve(NI), ckm8 = 2u * carve((NI + 1u) / 2u);      // ckm8: byte index; 0x80 | kept neighbours (bit j = ring slot j) of a clipped item, 0 for a kept one
         bool bad = false;
         WcScanState<2> st2;
+        // count: (clipped, new vertices); aux = kept mask | 0x80 | id << 8 | ring length << 24 (a kept cut point: id << 8)
         auto kfn = [&](uint32_t i, uint32_t& aux) -> uint2 {
-            const uint32_t id = clipped_id(i);
-            const WcRec r = rec_of(id);
+            uint32_t id; WcRec r;
+            if (i < nCo)
+            {
+                const WcW4 wr = g.grec[b0 + i];
+                stage_put(i, wr);
+                id = b0 + i; r = WcRec{wr.a, wr.b, wr.c, wr.d};
+            }
+            else
+            {
+                id = nin[i - nCo];
+                r = wc_rec(B, 8u * (id - WC_MAXN), true);
+                if ((r.tail() & 0xFFu) != k) { wc_st8(B, ckm8 + i, 0u); aux = id << 8; return make_uint2(0u, 0u); }
+            }
             // the first clipping plane of every cut point among the neighbours: all seven loads in flight together
             uint32_t ee[7], tl[7];
 #pragma unroll
@@ -494,45 +479,68 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             {
                 if ((((km & 3u) == 3u) && ee[0] == ee[1]) || (((km & 5u) == 5u) && ee[0] == ee[2]) || (((km & 6u) == 6u) && ee[1] == ee[2])) bad = true;
             }
-            wc_st8(B, ckm8 + i, km);
-            aux = km | (id << 8) | (((r.tail() >> 8) & 7u) << 24);
-            return make_uint2((uint32_t)__builtin_popcount(km), 0u);
+            wc_st8(B, ckm8 + i, km | 0x80u);
+            aux = km | 0x80u | (id << 8) | (((r.tail() >> 8) & 7u) << 24);
+            return make_uint2(1u, (uint32_t)__builtin_popcount(km));
         };
-        const uint32_t M = wc_scan_count<2>(W, sc, nC, st2, kfn, [&]() {}).x;
+        const uint2 nt = wc_scan_count<2>(W, sc, NI, st2, kfn, [&]() {});
+        WSTAMP(2);
+        const uint32_t nC = nt.x, M = nt.y, nCn = nC - nCo, keepn = nl - nCn;
+        const uint32_t dropAlive = SURTR_UNIFORM(W.hist[k]);
+        const uint32_t dropKept = dropAlive - SURTR_UNIFORM(W.zhist[k]);      // dropped vertices strictly on the kept side
+        if (nLive <= nC && dropKept == 0u)
+        {
+            if (nC == 0u) WC_RET(5);                 // every vertex in the plane: the bounding-box rule (:296-299) of the general clipper
+            nLive = 0; break;                             // "below": everything goes (:322-327)
+        }
+        if (nC == 0u)
+        {
+            // (nothing is clipped: the list of alive cut points stays where it is)
+            if (nLive + dropAlive < 4u) { nLive = 0; break; }      // (:497-499)
+            continue;
+        }
         if (M > 4095u || keepn + M > LT::kNL || nfree + nCn > LT::kNL) WC_RET(9);
         const uint32_t bmw = (M + 31u) / 32u;
-        if (4u * rtop + 3u * M + 2u * bmw + 2u * nC + 64u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
-        const uint32_t src = carve(M), srcid = carve(M), wst = carve(M), nd = carve(2u * nC), bm = carve(2u * bmw);
-        // ---- record units of the new vertices: those of cut points that are gone first (from the end of the free list), then the
-        //      end of the pool ----
-        const uint32_t fromf = nfree < M ? nfree : M, fromt = M - fromf, fbase = nfree, tbase = rtop;
+        if (4u * rtop + 3u * M + 2u * bmw + 2u * nl + nCn + 72u > ltop) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(10); }
+        const uint32_t src = carve(M), srcid = carve(M), wst = carve(M), nd = carve(2u * nl), bm = carve(2u * bmw), clist = carve(nCn);      // clist: item indices of the clipped cut points
+        // ---- record units of the new vertices: those of cut points that are gone first (the free list is a ring: taken at its
+        //      head, the units of this plane's clipped cut points are put behind its end while the list is placed), then the end
+        //      of the pool ----
+        const uint32_t fromf = nfree < M ? nfree : M, fromt = M - fromf, fh0 = fhead, fpush = fhead + nfree, tbase = rtop;
         {
             const uint32_t room = ltop / 4u > rtop ? ltop / 4u - rtop : 0u;
             if (fromt > room || rtop + fromt > capPool) { if (tid == 0u && atomicAdd(&why[20], 1u) == 3u) { why[21] = n; why[22] = k; why[23] = rtop; why[24] = M; why[25] = nC; why[26] = nl; why[27] = ltop; why[28] = nfree; } WC_RET(16); }
-            nfree -= fromf; rtop += fromt;
+            rtop += fromt;
+            fhead += fromf; if (fhead >= LT::kNL) fhead -= LT::kNL;
+            nfree = nfree - fromf + nCn;
         }
-        auto xof = [&](uint32_t t) -> uint32_t { return WC_MAXN + (t < fromf ? (uint32_t)W.freel[fbase - 1u - t] : tbase + (t - fromf)); };
+        auto fring = [&](uint32_t at) -> uint32_t { return at >= LT::kNL ? at - LT::kNL : at; };      // (at < 2 * kNL)
+        auto xof = [&](uint32_t t) -> uint32_t { return WC_MAXN + (t < fromf ? (uint32_t)W.freel[fring(fh0 + t)] : tbase + (t - fromf)); };
         for (uint32_t q = tid; q < bmw; q += G) wc_st32(B, bm + 2u * q, 0u);
         WSTAMP(3);
         WCOUNT(18, 1); WCOUNT(19, nC); WCOUNT(20, M); WCOUNT(21, nl);
 #ifdef SURTR_STAMP
         if (tid == 0u) { const unsigned long long need = 2ull * (4u * rtop + (8u * LT::kNR - ltop)); if (need > W.ph[31]) W.ph[31] = need; if (k >= 2u && need > W.ph[29]) W.ph[29] = need; }
 #endif
-        // ---- every clipped vertex gets its position in the list into its tail; source (clipped vertex, slot) of every new
-        //      vertex, in the reference's order (:333-357) ----
+        // ---- every clipped vertex gets its item index into its tail; source (clipped vertex, slot) of every new vertex, in the
+        //      reference's order (:333-357); the kept cut points move to the other list, in order ----
         // (blocks beyond those held in registers: the mask is read back, not derived again -- tails are being rewritten by now)
         auto kfn2 = [&](uint32_t i, uint32_t& aux) -> uint2 {
             const uint32_t id = clipped_id(i), km = wc_ld8(B, ckm8 + i);
+            if (!(km & 0x80u)) { aux = id << 8; return make_uint2(0u, 0u); }
             aux = km | (id << 8) | (((wc_ld16(B, t16_of(id)) >> 8) & 7u) << 24);
-            return make_uint2((uint32_t)__builtin_popcount(km), 0u);
+            return make_uint2(1u, (uint32_t)__builtin_popcount(km & 0x7Fu));
         };
-        wc_scan_place<2>(nC, st2, kfn2, [&](uint32_t i, uint32_t xm, uint32_t, uint2, uint32_t aux) {
-            const uint32_t km = aux & 0xFFu, id = (aux >> 8) & 0xFFFFu, len = aux >> 24;
+        wc_scan_place<2>(NI, st2, kfn2, [&](uint32_t i, uint32_t xc, uint32_t xm, uint2 c, uint32_t aux) {
+            const uint32_t km = aux & 0x7Fu, id = (aux >> 8) & 0xFFFFu, len = aux >> 24;
+            if (!c.x) { nout[i - xc] = (uint16_t)id; return; }      // (a kept cut point: every original before it is clipped)
             wc_st16(B, cbase + i, xm);
             wc_st16(B, t16_of(id), 0x8000u | (len << 12) | i);
+            if (i >= nCo) { W.freel[fring(fpush + (xc - nCo))] = (uint16_t)(id - WC_MAXN); wc_st16(B, clist + (xc - nCo), i); }
             uint32_t t = xm;
             for (uint32_t m = km; m; m &= m - 1u, ++t) { wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12)); wc_st16(B, srcid + t, id); }
         });
+        cur ^= 1u;
         __syncthreads();
         WSTAMP(4);
         // ---- successor of every new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j,
@@ -548,7 +556,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                 {
                     // a run of clipped vertices each entered through its slot 1 and left through its slot 0: the pointer
                     // jumping below collapsed it (clip_core.h does the same for its resumed walks)
-                    const uint32_t a = wc_ld32(B, nd + 2u * pcv), jx = a & 0xFFFFu;
+                    const uint32_t a = wc_ld32(B, nd + 2u * (pcv - nCo)), jx = a & 0xFFFFu;
                     if (jx != pcv) { pcv = jx; cv = clipped_id(jx); steps += a >> 16; rc = rec_of(cv); }
                 }
                 const uint32_t kmc = wc_ld8(B, ckm8 + pcv);
@@ -636,8 +644,9 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             // it moves on to e0 whenever slot 0 holds no kept vertex, and is there about to take slot 0 again when it arrives
             // through e0's slot 1
             // (only the cut points get an entry: the runs are runs of cap vertices; a walk that stands on an original steps on)
-            for (uint32_t i = nCo + tid; i < nC; i += G)
+            for (uint32_t ci = tid; ci < nCn; ci += G)
             {
+                const uint32_t i = wc_ld16(B, clist + ci);
                 const uint32_t c = clipped_id(i);
                 const WcRec r = rec_of(c);
                 const uint32_t e0 = r.e(0u);
@@ -648,21 +657,22 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                     const uint32_t t0 = r0.tail();
                     if ((t0 & 0x8000u) && r0.find(c, (t0 >> 12) & 7u) == 1u) { nx = t0 & 0xFFFu; d = 1u; }
                 }
-                wc_st32(B, nd + 2u * i, nx | (d << 16));
+                wc_st32(B, nd + 2u * (i - nCo), nx | (d << 16));
             }
             __syncthreads();
             for (uint32_t round = 0; round < 12u; ++round)
             {
                 bool ch = false;
-                for (uint32_t i = nCo + tid; i < nC; i += G)
+                for (uint32_t ci = tid; ci < nCn; ci += G)
                 {
+                    const uint32_t i = wc_ld16(B, clist + ci);
                     // (two levels per round: whatever value a lane reads is a vertex further down the same run, with its distance)
-                    const uint32_t a = wc_ld32(B, nd + 2u * i), j1 = a & 0xFFFFu;
+                    const uint32_t a = wc_ld32(B, nd + 2u * (i - nCo)), j1 = a & 0xFFFFu;
                     if (j1 == i) continue;
-                    const uint32_t b2 = wc_ld32(B, nd + 2u * j1), j2 = b2 & 0xFFFFu;
+                    const uint32_t b2 = wc_ld32(B, nd + 2u * (j1 - nCo)), j2 = b2 & 0xFFFFu;
                     if (j2 == j1) continue;
-                    const uint32_t b3 = wc_ld32(B, nd + 2u * j2), j3 = b3 & 0xFFFFu;
-                    wc_st32(B, nd + 2u * i, j3 | (((a >> 16) + (b2 >> 16) + (j3 != j2 ? (b3 >> 16) : 0u)) << 16));
+                    const uint32_t b3 = wc_ld32(B, nd + 2u * (j2 - nCo)), j3 = b3 & 0xFFFFu;
+                    wc_st32(B, nd + 2u * (i - nCo), j3 | (((a >> 16) + (b2 >> 16) + (j3 != j2 ? (b3 >> 16) : 0u)) << 16));
                     ch = true;
                 }
                 if (!wc_any(W, ac, ch, 0u)) break;
@@ -688,10 +698,8 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         if (wc_any(W, ac, fail || bad, 1u)) WC_RET(11);
         WSTAMP(8);
         zmask |= (unsigned long long)SURTR_UNIFORM(W.zm[0]) | ((unsigned long long)SURTR_UNIFORM(W.zm[1]) << 32);
-        // the cut points this plane clipped are gone: their units go to the free list (nobody takes from it before the next
-        // plane's kept masks are through a barrier)
-        for (uint32_t i = tid; i < nCn; i += G) W.freel[nfree + i] = (uint16_t)(wc_ld16(B, cnew + i) - WC_MAXN);
-        nfree += nCn;
+        // (the units of the cut points this plane clipped went to the free list with the scan; nobody takes from it before the
+        // next plane's scan is through its barrier)
         nLive = nLive - nC + M; nl = keepn + M;
         WSTAMP(9);
         if (nLive + dropAlive < 4u) { nLive = 0; break; }                          // (:497-499)

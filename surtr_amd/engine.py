@@ -54,11 +54,35 @@ def _use_library_for_tests(path):
     _LIB = _configure(ctypes.CDLL(path)) if path else None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64.  If libsurtr_hip.so is loaded first it brings in
+    /opt/rocm's runtime, a later `import torch` brings in the bundled one, and the second ROCr runtime of a process cannot open
+    the GPU ("No HIP GPUs are available").  A process that may use both (tests, bench.py, multigpu.py hand torch buffers to the
+    engine) therefore loads the runtime torch would load, first: libsurtr_hip.so's libamdhip64.so.N then resolves to it by
+    soname, which is what happens anyway when torch is imported before the engine.  Without torch installed this does nothing."""
+    import sys, importlib.util
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(lib_path()):
             raise ImportError("libsurtr_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _share_hip_runtime_with_torch()
         L = _configure(ctypes.CDLL(lib_path()))
         _LIB = L
     return _LIB
