@@ -131,6 +131,7 @@ struct alignas(16) WcLdsT
     uint32_t bst[WC_MAXF + 2];                // first id of bucket k (bucket F: never clipped); bst[F + 1] = n
     uint32_t wcnt[SURTR_NWAVE][WC_MAXF + 2];  // loader: originals per (wave, bucket)
     uint32_t wsum[2][2 * SURTR_NWAVE];        // ordered scans: totals per wave (two sets, alternating)
+    uint32_t bsum[2][2u * (4096u / SURTR_LANES)];   // the item scan: totals per 64-item block (two sets, alternating)
     uint32_t fl[3][2];                        // group-wide flags, three sets in rotation (see wc_any)
     uint32_t zm[2];                           // planes some cut point lies in
     uint32_t misc[8];
@@ -289,6 +290,98 @@ __device__ __forceinline__ void wc_scan_place(uint32_t N, WcScanState<NC>& st, C
     }
 }
 
+// The item scan of the plane loop: the same contract as wc_scan_count / wc_scan_place (counts of the first NC blocks of a wave
+// stay in registers), but 64-item block b belongs to wave b % waves -- a plane's originals, whose records come from global
+// memory, are the first blocks: this way every wave has at most a few of them and LDS-only blocks to work on meanwhile.
+// pref(i) fetches what count(i, aux&, fetched) needs from far away; the fetches of a wave's first NC blocks are issued before
+// anything is counted, and the blocks are counted last to first.  At most 4096 items (64 blocks of 64).
+template <int NC> struct WcRRState { uint2 cc[NC], ss[NC], px; uint32_t ax[NC]; };
+template <int NC, class LT, class PF, class C, class M>
+__device__ __forceinline__ uint2 wc_rr_count(LT& W, uint32_t& sc, uint32_t N, WcRRState<NC>& st, PF pref, C count, M mid)
+{
+    const uint32_t lane = lane_id(), w = wave_id(), nw = group_waves();
+    const uint32_t nb = (N + SURTR_LANES - 1u) >> SURTR_LSH;
+    uint32_t* bs = W.bsum[sc & 1u];
+    ++sc;
+    WcW4 pf[NC];
+#pragma unroll
+    for (int bi = 0; bi < NC; ++bi)
+    {
+        const uint32_t b = w + (uint32_t)bi * nw, i = (b << SURTR_LSH) + lane;
+        pf[bi] = WcW4{0u, 0u, 0u, 0u};
+        if (b < nb && i < N) pf[bi] = pref(i);
+    }
+#pragma unroll
+    for (int bi = NC - 1; bi >= 0; --bi)
+    {
+        const uint32_t b = w + (uint32_t)bi * nw, i = (b << SURTR_LSH) + lane;
+        st.cc[bi] = make_uint2(0u, 0u); st.ax[bi] = 0u; st.ss[bi] = make_uint2(0u, 0u);
+        if (b < nb)
+        {
+            if (i < N) st.cc[bi] = count(i, st.ax[bi], pf[bi]);
+            st.ss[bi] = wave_incl_scan2(st.cc[bi]);
+            if (lane == SURTR_LANES - 1u) { bs[2u * b] = st.ss[bi].x; bs[2u * b + 1u] = st.ss[bi].y; }
+        }
+    }
+    for (uint32_t b = w + (uint32_t)NC * nw; b < nb; b += nw)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        uint2 c = make_uint2(0u, 0u);
+        if (i < N) { uint32_t a; c = count(i, a, pref(i)); }
+        const uint2 s2 = wave_incl_scan2(c);
+        if (lane == SURTR_LANES - 1u) { bs[2u * b] = s2.x; bs[2u * b + 1u] = s2.y; }
+    }
+    mid();
+    __syncthreads();
+    // exclusive prefix of the block totals: lane l of every wave holds block (chunk + l)'s; a wave keeps those of its own blocks
+    uint2 run = make_uint2(0u, 0u);
+    st.px = make_uint2(0u, 0u);
+    for (uint32_t c0 = 0; c0 < nb; c0 += SURTR_LANES)
+    {
+        const uint32_t b = c0 + lane;
+        const uint2 v = b < nb ? make_uint2(bs[2u * b], bs[2u * b + 1u]) : make_uint2(0u, 0u);
+        const uint2 inc = wave_incl_scan2(v);
+        // (one chunk on the device: at most 64 blocks, kept in px; the single-lane, single-thread build of the tests has one
+        //  block per chunk and turns the totals into prefixes where they are)
+        if (SURTR_LANES > 1u) st.px = make_uint2(run.x + inc.x - v.x, run.y + inc.y - v.y);
+        else if (b < nb) { bs[2u * b] = run.x + inc.x - v.x; bs[2u * b + 1u] = run.y + inc.y - v.y; }      // (one thread: in place)
+        run.x += lane_bcast(inc.x, SURTR_LANES - 1u); run.y += lane_bcast(inc.y, SURTR_LANES - 1u);
+    }
+    return make_uint2(SURTR_UNIFORM(run.x), SURTR_UNIFORM(run.y));
+}
+// exclusive prefix of block b (uniform)
+template <int NC, class LT>
+__device__ __forceinline__ uint2 wc_rr_base(LT& W, const uint32_t* bs, const WcRRState<NC>& st, uint32_t b)
+{
+    if (SURTR_LANES > 1u) return make_uint2(lane_bcast(st.px.x, b), lane_bcast(st.px.y, b));
+    return make_uint2(bs[2u * b], bs[2u * b + 1u]);
+}
+template <int NC, class LT, class C, class P>
+__device__ __forceinline__ void wc_rr_place(LT& W, uint32_t sc_after, uint32_t N, WcRRState<NC>& st, C count, P place)
+{
+    const uint32_t lane = lane_id(), w = wave_id(), nw = group_waves();
+    const uint32_t nb = (N + SURTR_LANES - 1u) >> SURTR_LSH;
+    const uint32_t* bs = W.bsum[(sc_after - 1u) & 1u];
+#pragma unroll
+    for (int bi = 0; bi < NC; ++bi)
+    {
+        const uint32_t b = w + (uint32_t)bi * nw, i = (b << SURTR_LSH) + lane;
+        if (b >= nb) break;
+        const uint2 base = wc_rr_base<NC>(W, bs, st, b);
+        const uint2 c = st.cc[bi], s2 = st.ss[bi];
+        if (i < N) place(i, base.x + s2.x - c.x, base.y + s2.y - c.y, c, st.ax[bi]);
+    }
+    for (uint32_t b = w + (uint32_t)NC * nw; b < nb; b += nw)
+    {
+        const uint32_t i = (b << SURTR_LSH) + lane;
+        const uint2 base = wc_rr_base<NC>(W, bs, st, b);
+        uint2 c = make_uint2(0u, 0u); uint32_t a = 0u;
+        if (i < N) c = count(i, a);
+        const uint2 s2 = wave_incl_scan2(c);
+        if (i < N) place(i, base.x + s2.x - c.x, base.y + s2.y - c.y, c, a);
+    }
+}
+
 __device__ __forceinline__ uint32_t wc_popc64(unsigned long long m) { return (uint32_t)__builtin_popcountll(m); }
 
 // Sorts the band: stable counting sort by first clipping plane; records and positions of the originals go to the workgroup's
@@ -440,13 +533,14 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : (uint32_t)nin[i - nCo]; };
         const uint32_t cbase = carve(NI), ckm8 = 2u * carve((NI + 1u) / 2u);      // ckm8: byte index; 0x80 | kept neighbours (bit j = ring slot j) of a clipped item, 0 for a kept one
         bool bad = false;
-        WcScanState<2> st2;
+        WcRRState<2> st2;
+        // what an item needs from global memory: the record of an original
+        auto pfn = [&](uint32_t i) -> WcW4 { return i < nCo ? g.grec[b0 + i] : WcW4{0u, 0u, 0u, 0u}; };
         // count: (clipped, new vertices); aux = kept mask | 0x80 | id << 8 | ring length << 24 (a kept cut point: id << 8)
-        auto kfn = [&](uint32_t i, uint32_t& aux) -> uint2 {
+        auto kfn = [&](uint32_t i, uint32_t& aux, const WcW4 wr) -> uint2 {
             uint32_t id; WcRec r;
             if (i < nCo)
             {
-                const WcW4 wr = g.grec[b0 + i];
                 stage_put(i, wr);
                 id = b0 + i; r = WcRec{wr.a, wr.b, wr.c, wr.d};
             }
@@ -461,29 +555,32 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
 #pragma unroll
             for (uint32_t q = 0; q < 7u; ++q) ee[q] = r.e(q);
 #pragma unroll
-            for (uint32_t q = 0; q < 7u; ++q) tl[q] = wc_ld16(B, (ee[q] >= WC_MAXN && ee[q] < WC_SENT) ? 4u * (ee[q] - WC_MAXN) + 3u : 3u);
+            for (uint32_t q = 0; q < 7u; ++q) tl[q] = wc_ld16(B, ((ee[q] >= WC_MAXN ? 1u : 0u) & (ee[q] < WC_SENT ? 1u : 0u)) ? 4u * (ee[q] - WC_MAXN) + 3u : 3u);
             uint32_t km = 0;
 #pragma unroll
             for (uint32_t q = 0; q < 7u; ++q)
             {
                 // an original is kept when it sits in a later bucket, a cut point when its own first clipping plane is later;
                 // a dropped vertex (WC_SENT) goes with this plane
-                const bool kept = ee[q] < WC_MAXN ? ee[q] >= b1 : (ee[q] < WC_SENT && (tl[q] & 0xFFu) > k);
-                if (kept) km |= 1u << q;
+                // (bitwise, not short-circuit: the compiler turns && / ?: on lane values into exec-mask branches, seven times over)
+                const uint32_t isO = ee[q] < WC_MAXN ? 1u : 0u;
+                const uint32_t kept = (isO & (ee[q] >= b1 ? 1u : 0u)) | ((isO ^ 1u) & (ee[q] < WC_SENT ? 1u : 0u) & ((tl[q] & 0xFFu) > k ? 1u : 0u));
+                km |= kept << q;
             }
             // A ring that lists the same kept neighbour twice makes the back-link patch order dependent (:350-354).  The rings of
             // the originals list no vertex twice (the piece has none: Pieces::mdup, checked by the caller; a patch puts the cut
             // point of ONE edge into ONE entry), so only a cut point's ring can: [Z, Z, kept] of a cap of two vertices, or
             // [pred, succ, kept] with kept among them.
-            if (id >= WC_MAXN && (km & (km - 1u)))
             {
-                if ((((km & 3u) == 3u) && ee[0] == ee[1]) || (((km & 5u) == 5u) && ee[0] == ee[2]) || (((km & 6u) == 6u) && ee[1] == ee[2])) bad = true;
+                const uint32_t d01 = ((km & 3u) == 3u ? 1u : 0u) & (ee[0] == ee[1] ? 1u : 0u), d02 = ((km & 5u) == 5u ? 1u : 0u) & (ee[0] == ee[2] ? 1u : 0u),
+                               d12 = ((km & 6u) == 6u ? 1u : 0u) & (ee[1] == ee[2] ? 1u : 0u);
+                bad = bad | (((id >= WC_MAXN ? 1u : 0u) & (d01 | d02 | d12)) != 0u);
             }
             wc_st8(B, ckm8 + i, km | 0x80u);
             aux = km | 0x80u | (id << 8) | (((r.tail() >> 8) & 7u) << 24);
             return make_uint2(1u, (uint32_t)__builtin_popcount(km));
         };
-        const uint2 nt = wc_scan_count<2>(W, sc, NI, st2, kfn, [&]() {});
+        const uint2 nt = wc_rr_count<2>(W, sc, NI, st2, pfn, kfn, [&]() { WSTAMP(14); });
         WSTAMP(2);
         const uint32_t nC = nt.x, M = nt.y, nCn = nC - nCo, keepn = nl - nCn;
         const uint32_t dropAlive = SURTR_UNIFORM(W.hist[k]);
@@ -531,7 +628,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             aux = km | (id << 8) | (((wc_ld16(B, t16_of(id)) >> 8) & 7u) << 24);
             return make_uint2(1u, (uint32_t)__builtin_popcount(km & 0x7Fu));
         };
-        wc_scan_place<2>(NI, st2, kfn2, [&](uint32_t i, uint32_t xc, uint32_t xm, uint2 c, uint32_t aux) {
+        wc_rr_place<2>(W, sc, NI, st2, kfn2, [&](uint32_t i, uint32_t xc, uint32_t xm, uint2 c, uint32_t aux) {
             const uint32_t km = aux & 0x7Fu, id = (aux >> 8) & 0xFFFFu, len = aux >> 24;
             if (!c.x) { nout[i - xc] = (uint16_t)id; return; }      // (a kept cut point: every original before it is clipped)
             wc_st16(B, cbase + i, xm);
@@ -541,6 +638,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             for (uint32_t m = km; m; m &= m - 1u, ++t) { wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12)); wc_st16(B, srcid + t, id); }
         });
         cur ^= 1u;
+        WSTAMP(15);
         __syncthreads();
         WSTAMP(4);
         // ---- successor of every new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j,
@@ -564,7 +662,7 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
                 if (steps >= limit) return WC_NONE;
                 const uint32_t e = rc.e(p);
                 // the next vertex must be one this plane clips: an original of its bucket or a cut point (checked by its tail)
-                if (e >= WC_SENT || (e < WC_MAXN && (e < b0 || e >= b1)) || steps + 2u >= nref)
+                if (((e >= WC_SENT ? 1u : 0u) | ((e < WC_MAXN ? 1u : 0u) & ((e < b0 ? 1u : 0u) | (e >= b1 ? 1u : 0u))) | (steps + 2u >= nref ? 1u : 0u)) != 0u)
                 { SURTR_DBG("  wc walk: sentinel / not clipped / bound e=%u steps=%u nref=%u k=%u\n", e, steps, nref, k); fail = true; return WC_NONE; }
                 ++steps;
                 const WcRec re = rec_of(e);
@@ -582,7 +680,8 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         auto arrive = [&](uint32_t t, uint32_t end) {
             wc_st16(B, wst + t, 0xFFFFu);
             uint32_t* word = (uint32_t*)(void*)(B + 2u * (size_t)(bm + 2u * (end >> 5)));
-            if (end == t || (atomicOr(word, 1u << (end & 31u)) & (1u << (end & 31u)))) { SURTR_DBG("  wc walk: ends on itself / second arrival t=%u end=%u k=%u\n", t, end, k); fail = true; }
+            const uint32_t before = atomicOr(word, 1u << (end & 31u));
+            if (((end == t ? 1u : 0u) | ((before >> (end & 31u)) & 1u)) != 0u) { SURTR_DBG("  wc walk: ends on itself / second arrival t=%u end=%u k=%u\n", t, end, k); fail = true; }
             const uint32_t X = xof(t), Z = xof(end);
             wc_st16(B, 4u * (Z - WC_MAXN), X);
             wc_st16(B, 4u * (X - WC_MAXN) + 1u, Z);
@@ -602,8 +701,9 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
             uint32_t pcv = s & 0xFFFu, cv = v;
             WcRec rc = rec_of(cv);
             const uint32_t u = rc.e(j);
-            const float4 pa = v < WC_MAXN ? g.gpos[v] : g.cpos[v - WC_MAXN];
-            const float4 pb = u < WC_MAXN ? g.gpos[u] : g.cpos[u - WC_MAXN];
+            // (one load each through a selected address: gpos and cpos are parts of the same scratch slot)
+            const float4 pa = *(v < WC_MAXN ? g.gpos + v : g.cpos + (v - WC_MAXN));
+            const float4 pb = *(u < WC_MAXN ? g.gpos + u : g.cpos + (u - WC_MAXN));
             // the kept end: an original lives in global memory, a cut point in LDS
             WcW4 wru = WcW4{0u, 0u, 0u, 0u};
             if (u < WC_MAXN) wru = g.grec[u];
