@@ -256,7 +256,7 @@ def main():
     E = len(engs)
     for e in engs:
         e.set_profiling(True)
-    rounds = 5
+    rounds = 12
     for _ in range(rounds * E):
         step()
     fence()
@@ -331,7 +331,12 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": ab["clip_kernel"], "event_algorithmic_bytes": ab["event"],
-                         "avg_launch_ms": clip_avg_ms},
+                         "avg_launch_ms": clip_avg_ms,
+                         # the same kernel with nothing else on the GPU (one event at a time): with several events in flight a
+                         # launch shares the CUs with the kernels of the other events and its duration depends on how the
+                         # streams happen to interleave
+                         "launch_ms_min_max": [float(np.min(clip_ms)), float(np.max(clip_ms))], "launches_timed": len(clip_ms),
+                         "avg_launch_ms_alone": float(np.mean(all_ms.get(dom[2:], [0.0])))},
         }
         out["setup"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in setup_ms.items()}
         if other_extra is not None:
