@@ -117,7 +117,10 @@ int surtr_kernel_history(surtr_ctx* ctx, float ms[16], int slot[16], uint32_t* n
 /* Diagnostic: the device-side counters of the last event (synchronises the stream).  out[0..3] arena use (vertices, ring
  * entries, indices, islands), [5] status, [16+c] pairs of cost class c handed to k_clip_pairs(_big), [32+c] fragments of size
  * class c, [48+c] pairs of pre-pass class c, [64+c] pairs of class c handed to k_clip_pairs_half, [64] pairs that outgrew
- * its half-size LDS topology and were redone by k_clip_pairs. */
+ * its half-size LDS topology and were redone by k_clip_pairs, [88] / [89] pairs the record clipper took / handed on to the
+ * general clipper ([96+r]: by rule r), [90] solids that were too large for the literal last-resort clipper (more than 32 ring
+ * entries at a vertex, or more vertices than its scratch): their pair / fragment is flagged like one without a valid result in
+ * the reference -- this counter is how to tell the engine's limit from the reference's undefined behaviour. */
 int surtr_queue_stats(surtr_ctx* ctx, uint32_t out[128]);
 /* Diagnostic: the status of every pair of the last event (0, or the SURTR_E_* code that pair raised), in pair order
  * (cell-major for surtr_fracture_event, list order for surtr_fracture_pairs).  Works after an event that failed. */

@@ -546,7 +546,8 @@ __device__ static bool solid_is_sliver(const SolidIn in)
 }
 
 struct LitRun { int err; uint32_t n, nh; LitSolid LS; const uint32_t* off; bool stale; };
-__device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp, bool ids_set = false)
+__device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Shared* shp, bool ids_set = false,
+                                                                uint32_t* too_big = nullptr)
 {
     Shared& sh = *shp;
     Scratch S = carve(pool, wg);
@@ -557,7 +558,12 @@ __device__ __attribute__((noinline)) static LitRun literal_run(SolidIn in, uint3
     {
         uint32_t n = 0; bool stale = false;
         int rc = literal_clip(in, F, sh.planes, r.LS, &n, &stale, ids_set);
-        if (rc == SURTR_E_CAPACITY) rc = SURTR_E_TOPOLOGY;          // too large for the literal path: the first error stands
+        // Too large for the literal path (a ring of more than LIT_STRIDE entries, more vertices than its scratch holds).  The
+        // solids that come here are those the parallel clippers cannot answer for (a walk they cannot follow, or a ring that
+        // lists a neighbour twice, on which they differ from the reference), so there is nobody left to ask: the first error
+        // stands -- the pair or fragment is flagged as for a case without a valid result in the reference -- and the case is
+        // counted (surtr_queue_stats out[90]) so that a host can tell an engine limit from the reference's undefined behaviour.
+        if (rc == SURTR_E_CAPACITY) { rc = SURTR_E_TOPOLOGY; if (too_big != nullptr) atomicAdd(too_big, 1u); }
         uint32_t h = 0;
         if (rc == 0) for (uint32_t v = 0; v < n; ++v) { S.aux1[v] = h; h += r.LS.len[v]; }
         sh.misc[2] = (uint32_t)rc; sh.misc[3] = n; sh.misc[4] = h; sh.misc[5] = stale ? 1u : 0u;
@@ -581,7 +587,7 @@ __device__ static void literal_write(const LitRun& r, float* pos, uint32_t* loff
 }
 __device__ __attribute__((noinline)) static ParkOut solid_literal(SolidIn in, uint32_t F, ScratchPool pool, uint32_t wg, Arena A, Shared* shp, bool ids_set = false)
 {
-    const LitRun r = literal_run(in, F, pool, wg, shp, ids_set);
+    const LitRun r = literal_run(in, F, pool, wg, shp, ids_set, &A.cursors[90]);
     ParkOut o{r.err, 0u, 0u, 0u, 0u, r.stale};
     if (r.err != 0 || r.n == 0u) return o;
     uint32_t ioff;
