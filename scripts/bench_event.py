@@ -20,6 +20,7 @@ for _ in range(10):
     eng.fracture_event(0, 4096)
     for k, v in eng.kernel_times().items():
         if v >= 0: acc.setdefault(k, []).append(v)
-print("%s: event ms min %.3f median %.3f | kernels (median ms) %s" % (os.environ.get("SURTR_LIB", "default"), ts[0], ts[len(ts) // 2],
-      {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
+q = eng.queue_stats()
+print("%s: event ms min %.3f median %.3f | record clipper took %d handed on %d | kernels (median ms) %s" % (os.environ.get("SURTR_LIB", "default"), ts[0], ts[len(ts) // 2],
+      int(q[88]), int(q[89]), {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
 eng.close()
