@@ -1771,6 +1771,9 @@ __device__ __attribute__((always_inline)) static inline uint32_t ear_clip_small(
     return at + 3;
 }
 
+#ifndef SURTR_EAR_WAVE_MAX
+#define SURTR_EAR_WAVE_MAX 256u      // faces of up to this many vertices are triangulated by a wave (64 * K vertices, K per lane)
+#endif
 #if SURTR_LANES == 64
 // Poly::EarClipping for one face of 5..64 vertices on one wave: lane i holds vertex i (position, prev/next
 // link, reflex flag) in registers; the sequential ear loop (:868-906) runs wave-uniformly, and the scan of the
@@ -1865,6 +1868,147 @@ __device__ __attribute__((always_inline)) static inline uint32_t ear_clip_face_w
     }
     {
         const int p = EAR_BCAST(prv, cur), n = EAR_BCAST(nxt, cur);
+        if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
+    }
+    return at + 3;
+}
+
+// The same for a face of up to 64 * K vertices: lane l holds the vertices l, l + 64, ... (K of them) in registers.  Every index
+// the sequential loop works with is wave-uniform, so "vertex i" is slot i / 64 of lane i % 64: K lane reads and a scalar select.
+// The cap of a cell on a piece of 100 000 vertices and more has that many vertices; one lane walking it with its prev / next /
+// reflex arrays in global memory (ear_clip_face) took milliseconds.  Same triangles, same order, same stall rule.
+// (out of line, on the global copies of positions and loops: such faces are rare in fragments small enough for the LDS staging, and
+// inlined twice the function cost the common path registers -- k_faces 0.36 -> 0.39 ms on configs[3])
+template <int K, class LP>
+__device__ __attribute__((noinline)) static uint32_t ear_clip_face_wave_k(const float* pos, const LP* loop, int N, uint32_t* out)
+{
+    const int lane = (int)lane_id();
+    float x[K], y[K], z[K]; int prv[K], nxt[K]; bool rfx[K], mine[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+    {
+        const int v = lane + 64 * j;
+        mine[j] = v < N;
+        const int32_t vid = (int32_t)loop[mine[j] ? v : 0];
+        x[j] = pos[3 * vid]; y[j] = pos[3 * vid + 1]; z[j] = pos[3 * vid + 2];
+        prv[j] = (v + N - 1) % N; nxt[j] = (v + 1) % N; rfx[j] = false;
+    }
+    // value of vertex i (wave-uniform i)
+    auto bf = [&](const float (&a)[K], int i) -> float {
+        const int jj = i >> 6; const uint32_t l = (uint32_t)(i & 63);
+        float r = lane_bcast(a[0], l);
+#pragma unroll
+        for (int j = 1; j < K; ++j) { const float t = lane_bcast(a[j], l); r = jj == j ? t : r; }
+        return r;
+    };
+    auto bi = [&](const int (&a)[K], int i) -> int {
+        const int jj = i >> 6; const uint32_t l = (uint32_t)(i & 63);
+        int r = lane_bcast(a[0], l);
+#pragma unroll
+        for (int j = 1; j < K; ++j) { const int t = lane_bcast(a[j], l); r = jj == j ? t : r; }
+        return r;
+    };
+    auto bb = [&](const bool (&a)[K], int i) -> bool {
+        const int jj = i >> 6; const uint32_t l = (uint32_t)(i & 63);
+        int r = lane_bcast((int)a[0], l);
+#pragma unroll
+        for (int j = 1; j < K; ++j) { const int t = lane_bcast((int)a[j], l); r = jj == j ? t : r; }
+        return r != 0;
+    };
+    const float ax0 = bf(x, 0), ay0 = bf(y, 0), az0 = bf(z, 0);
+    float nx, ny, nz;
+    {
+        const float ux = bf(x, 1) - ax0, uy = bf(y, 1) - ay0, uz = bf(z, 1) - az0;
+        const float wx = bf(x, 2) - ax0, wy = bf(y, 2) - ay0, wz = bf(z, 2) - az0;
+        nx = uy * wz - uz * wy; ny = uz * wx - ux * wz; nz = ux * wy - uy * wx;
+    }
+    {   // IsCCW (:753-762): the sum runs over v = 0..N-1 in order (float addition is not associative)
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        float px_ = ax0, py_ = ay0, pz_ = az0;
+        for (int v = 0; v < N; ++v)
+        {
+            const int q = (v + 1) % N;
+            const float qx = bf(x, q), qy = bf(y, q), qz = bf(z, q);
+            const float ux = px_ - ax0, uy = py_ - ay0, uz = pz_ - az0;
+            const float wx = qx - ax0, wy = qy - ay0, wz = qz - az0;
+            sx = sx + (uy * wz - uz * wy); sy = sy + (uz * wx - ux * wz); sz = sz + (ux * wy - uy * wx);
+            px_ = qx; py_ = qy; pz_ = qz;
+        }
+        if (dot3(sx, sy, sz, nx, ny, nz) < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+    }
+    auto right_of = [&](float ax, float ay, float az, float bx_, float by_, float bz_, float cx, float cy, float cz) {
+        const float ux = bx_ - ax, uy = by_ - ay, uz = bz_ - az;
+        const float wx = cx - ax, wy = cy - ay, wz = cz - az;
+        const float kx = uy * wz - uz * wy, ky = uz * wx - ux * wz, kz = ux * wy - uy * wx;
+        return dot3(kx, ky, kz, nx, ny, nz) > 0.f;
+    };
+    // reflex flags: every lane fetches the neighbours of its own vertices (a real shuffle per slot of the source)
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+    {
+        float pxv = 0.f, pyv = 0.f, pzv = 0.f, qxv = 0.f, qyv = 0.f, qzv = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2)
+        {
+            const float tx = __shfl(x[s2], prv[j] & 63, 64), ty = __shfl(y[s2], prv[j] & 63, 64), tz = __shfl(z[s2], prv[j] & 63, 64);
+            if ((prv[j] >> 6) == s2) { pxv = tx; pyv = ty; pzv = tz; }
+            const float ux = __shfl(x[s2], nxt[j] & 63, 64), uy = __shfl(y[s2], nxt[j] & 63, 64), uz = __shfl(z[s2], nxt[j] & 63, 64);
+            if ((nxt[j] >> 6) == s2) { qxv = ux; qyv = uy; qzv = uz; }
+        }
+        rfx[j] = mine[j] && !right_of(pxv, pyv, pzv, x[j], y[j], z[j], qxv, qyv, qzv);
+    }
+    auto set_i = [&](int (&a)[K], int i, int val) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) if (lane == (i & 63) && (i >> 6) == j) a[j] = val;
+    };
+    int skipped = 0, left = N, cur = 0;
+    uint32_t at = 0;
+    while (left > 3)
+    {
+        const int p = bi(prv, cur), n = bi(nxt, cur);
+        bool ear = !bb(rfx, cur);
+        if (ear)
+        {
+            const float ax = bf(x, p), ay = bf(y, p), az = bf(z, p);
+            const float cx_ = bf(x, cur), cy_ = bf(y, cur), cz_ = bf(z, cur);
+            const float ex = bf(x, n), ey = bf(y, n), ez = bf(z, n);
+            bool inside = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+            {
+                const int v = lane + 64 * j;
+                if (mine[j] && rfx[j] && v != p && v != n)
+                {
+                    const bool same = (x[j] == ax && y[j] == ay && z[j] == az) || (x[j] == cx_ && y[j] == cy_ && z[j] == cz_);
+                    if (!same && right_of(ax, ay, az, cx_, cy_, cz_, x[j], y[j], z[j]) && right_of(cx_, cy_, cz_, ex, ey, ez, x[j], y[j], z[j]) &&
+                        right_of(ex, ey, ez, ax, ay, az, x[j], y[j], z[j])) inside = true;
+                }
+            }
+            ear = __ballot(inside) == 0ull;
+        }
+        if (ear)
+        {
+            if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
+            set_i(nxt, p, n);
+            set_i(prv, n, p);
+            // reflex flags of the two neighbours, only if they were reflex (:885-893)
+            const int np = bi(prv, p), nn = bi(nxt, n);
+            const float npx = bf(x, np), npy = bf(y, np), npz = bf(z, np), nnx = bf(x, nn), nny = bf(y, nn), nnz = bf(z, nn);
+            const float ppx = bf(x, p), ppy = bf(y, p), ppz = bf(z, p), qqx = bf(x, n), qqy = bf(y, n), qqz = bf(z, n);
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+            {
+                const int v = lane + 64 * j;
+                if (v == p && rfx[j]) rfx[j] = !right_of(npx, npy, npz, x[j], y[j], z[j], qqx, qqy, qqz);
+                if (v == n && rfx[j]) rfx[j] = !right_of(ppx, ppy, ppz, x[j], y[j], z[j], nnx, nny, nnz);
+            }
+            at += 3; --left; skipped = 0;
+        }
+        else if (++skipped > left) return 0;             // stalled: the face is dropped (:899-903)
+        cur = n;
+    }
+    {
+        const int p = bi(prv, cur), n = bi(nxt, cur);
         if (lane == 0) { out[at] = (uint32_t)loop[p]; out[at + 1] = (uint32_t)loop[cur]; out[at + 2] = (uint32_t)loop[n]; }
     }
     return at + 3;
@@ -2241,7 +2385,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
             if (tid == 0) { face_off[nfaces] = lensum; face_n[0] = nfaces; face_n[1] = lensum; }
         }
         STAMP(62);
-        // 4. triangulate: faces of 5..64 vertices one per wave (registers only), the others one per lane;
+        // 4. triangulate: faces of 5..256 vertices one per wave (registers only), the others one per lane;
         //    room for 3*len indices at 3*lo.  The arrays of the face search are dead now: a small fragment's positions and
         //    loops go there, so that the ear tests read LDS instead of waiting for global memory vertex by vertex.
         const bool ear_lds = !fan && n <= FL_V && lensum <= FL_J;
@@ -2273,14 +2417,15 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
             const uint32_t fl = f0 + lane_id();
             uint32_t mylo = 0, mylen = 0;
             if (fl < nfaces) { mylo = (uint32_t)faceLo[fl]; mylen = (uint32_t)faceLen[fl]; }
-            unsigned long long todo = __ballot(mylen >= 5u && mylen <= 64u);
+            unsigned long long todo = __ballot(mylen >= 5u && mylen <= SURTR_EAR_WAVE_MAX);
             for (uint32_t ord = 0; todo != 0ull; todo &= todo - 1ull, ++ord)
             {
                 if (ord % group_waves() != wave_id()) continue;
                 const uint32_t src = (uint32_t)__builtin_ctzll(todo);
                 const uint32_t lo = lane_bcast(mylo, src), len = lane_bcast(mylen, src);
                 uint32_t cnt;
-                if (ear_lds) cnt = ear_clip_face_wave((const float*)FU.ear.pos, (const uint16_t*)FU.ear.loop + lo, (int)len, tri + 3u * (size_t)lo);
+                if (len > 64u) cnt = ear_clip_face_wave_k<SURTR_EAR_WAVE_MAX / 64>(pos, (const int32_t*)loopbuf + lo, (int)len, tri + 3u * (size_t)lo);      // (several vertices per lane)
+                else if (ear_lds) cnt = ear_clip_face_wave((const float*)FU.ear.pos, (const uint16_t*)FU.ear.loop + lo, (int)len, tri + 3u * (size_t)lo);
                 else cnt = ear_clip_face_wave(pos, (const int32_t*)loopbuf + lo, (int)len, tri + 3u * (size_t)lo);
                 if (lane_id() == 0) fcnt[f0 + src] = cnt;
             }
@@ -2292,7 +2437,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
         {
             const uint32_t lo = (uint32_t)faceLo[fi], len = (uint32_t)faceLen[fi];
 #if SURTR_LANES == 64
-            if (len >= 5u && len <= 64u) continue;
+            if (len >= 5u && len <= SURTR_EAR_WAVE_MAX) continue;
 #endif
             uint32_t* out = tri + 3u * (size_t)lo;
             uint32_t cnt = 0u;

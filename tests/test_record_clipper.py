@@ -160,5 +160,9 @@ def test_record_clipper_big_bands_kernel_gpu(gpu_engine, oracle, monkeypatch, bi
             for j, k in enumerate(ks):
                 a, b = fragment(whole, int(k), "mesh"), fragment(ref, j, "mesh")
                 assert np.array_equal(a["off"], b["off"]) and np.array_equal(a["nbr"], b["nbr"]) and np.array_equal(a["pos"], b["pos"])
+                # triangles too: the cap of a cell on this piece has up to ~90 vertices -- faces of 65..256 vertices are ear-clipped
+                # by a wave with several vertices per lane (ear_clip_face_wave_k), the same triangles in the same order
+                i0, i1 = int(whole["idx_off"][k]), int(whole["idx_off"][k + 1]); r0, r1 = int(ref["idx_off"][j]), int(ref["idx_off"][j + 1])
+                assert np.array_equal(whole["idx"][i0:i1], ref["idx"][r0:r1])
     finally:
         eng.close()
