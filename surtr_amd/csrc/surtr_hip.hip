@@ -755,7 +755,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                          uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
@@ -892,7 +892,14 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             // their global scratch (class 13), all of them at once instead of a queue behind 48
             // (big_quota = all ones: the record clipper's whole-CU kernel takes the large bands -- those it can hold, narrow images of
             // fewer than WC_MAXN vertices; the others are spread over the regular kernel's workgroups as before)
-            if (big_quota == 0xFFFFFFFFu) { if (cls >= 14u && !(fmt == IMG_NARROW && n < WC_MAXN)) cls = 13u; }
+            if (big_quota == 0xFFFFFFFFu)
+            {
+                if (cls >= 14u && !(fmt == IMG_NARROW && n < WC_MAXN)) cls = 13u;
+                // ... and a band of more than big_n vertices that the general clipper's topology would still hold: its first planes
+                // clip thousands of vertices at once, more than the regular record clipper's 56 KB take (it would hand the pair on
+                // after the loader and a plane or two) -- the whole-CU variant has the room
+                else if (cls < 12u && fmt == IMG_NARROW && n > big_n && n < WC_MAXN) cls = 14u;
+            }
             else if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
             if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
@@ -911,12 +918,12 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota);
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -927,12 +934,12 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota);
+    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -3086,6 +3093,9 @@ static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pai
     return SURTR_OK;
 }
 
+#ifndef SURTR_WAVE_BIG_N
+#define SURTR_WAVE_BIG_N 2800u
+#endif
 static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
     (void)hipSetDevice(ctx->device);
@@ -3148,6 +3158,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_END(6);
     uint32_t big_quota = ctx->wave_big ? 0xFFFFFFFFu : 2u * ctx->n_wg_big;
     if (const char* e = getenv("SURTR_BIG_QUOTA")) big_quota = (uint32_t)atoi(e);      // (tests: 0 sends every big band to the regular kernel's global scratch)
+    // (pieces of 80 000 vertices and more: bands beyond this size go to the whole-CU record clipper, see k_prep_pairs)
+    // measured at 4 096 cells with 2 800: 100 000-vertex piece 6.50 -> 5.96 ms, 150 000 vertices 10.5 -> 9.6 ms, 210 000 vertices 12.6 -> 12.8 ms
+    // (there nearly every band is beyond it and the regular kernel runs dry): applied below 180 000 vertices
+    uint32_t big_n = (ctx->wave_big && ctx->vmax < 180000u) ? SURTR_WAVE_BIG_N : 0xFFFFFFFFu;
+    if (const char* e = getenv("SURTR_WAVE_BIG_N")) big_n = (uint32_t)atoi(e);
     PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
     uint32_t wide_max = 4u * ctx->max_wg;
@@ -3156,11 +3171,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
