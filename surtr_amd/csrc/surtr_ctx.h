@@ -73,7 +73,7 @@ struct Arena
     uint32_t capV, capH, capI, capIsl;
     uint32_t* cursors;   // [0]=V [1]=H [2]=I [3]=Isl [4]=clip queue [5]=status [6]=refit queue [7]=faces queue [8]=convex queue
                          // [9]=pre-pass queue [10]=image arena (16-byte units) [11]=big clip queue
-                         // [12]=half clip queue [13]=retry queue
+                         // [12]=half clip queue [13]=retry queue [14]=flagged fragments [15]=flagged pairs (n_failed = 14 + 15)
                          // [16..31]=pairs per cost class (k_prep_pairs) [32..47]=fragments per size class [48..63]=pairs per
                          // pre-pass class [64..79]=pairs per cost class of k_clip_pairs_half (64 = its retry list)
 };

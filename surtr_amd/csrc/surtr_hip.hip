@@ -277,7 +277,8 @@ __global__ void k_place_cells_groups(uint32_t nfaces, const float* __restrict__ 
 // error is the event's.
 __device__ __forceinline__ void pair_failed(const Arena& A, int err)
 {
-    if (err == SURTR_E_TOPOLOGY) atomicAdd(&A.cursors[14], 1u); else atomicMax(&A.cursors[5], (uint32_t)err);
+    // (cursor 15: pairs; cursor 14 counts flagged FRAGMENTS and is reset by a re-triangulation -- the pairs' count is the event's)
+    if (err == SURTR_E_TOPOLOGY) atomicAdd(&A.cursors[15], 1u); else atomicMax(&A.cursors[5], (uint32_t)err);
 }
 
 // ------------------------------------------------------------- arena output
@@ -2547,7 +2548,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ fra
     if (threadIdx.x == 0)
     {
         counts->mesh_verts = mv; counts->mesh_nbrs = mh; counts->conv_verts = cv; counts->conv_nbrs = chh;
-        counts->n_idx = t0; counts->status = A.cursors[5]; counts->n_failed = A.cursors[14];
+        counts->n_idx = t0; counts->status = A.cursors[5]; counts->n_failed = A.cursors[14] + A.cursors[15];
     }
 }
 
@@ -3394,7 +3395,7 @@ int surtr_event_refit(surtr_ctx* ctx)
 static int launch_faces(surtr_ctx* ctx, uint32_t fan, uint32_t* d_face_n, uint32_t* d_face_off, int32_t* d_face_idx)
 {
     hipStream_t st = ctx->stream;
-    // queue 7 = fragments for k_faces, cursor 2 = index arena, 14 = fragments without triangles
+    // queue 7 = fragments for k_faces, cursor 2 = index arena, 14 = flagged fragments (flagged pairs are counted in 15: they stay)
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 7, 0, 4, st));
     HIPCHK(hipMemsetAsync(ctx->arena.cursors + 2, 0, 4, st));
     if (!(ctx->last_flags & SURTR_EVT_REFIT))      // (a refit of these fragments may have flagged some: those flags stay)

@@ -416,7 +416,27 @@ std::vector<Fragment> FractureEngine::ApplyFracture(const std::set<int>& outside
     if (cellEnd == 0xFFFFFFFFu) cellEnd = n_cells_;
     const uint32_t flags = (refit ? SURTR_EVT_REFIT : 0u) | (render ? SURTR_EVT_RENDER : 0u);
     check(surtr_fracture_event(ctx_, cellBegin, cellEnd, outside.empty() ? nullptr : mask.data(), flags, &counts_), "surtr_fracture_event");
-    return download_fragments(render);
+    std::vector<Fragment> out = download_fragments(render);
+    report_flagged(out, cellBegin, cellEnd, "ApplyFracture");
+    return out;
+}
+
+// What the event flagged (surtr_counts::n_failed): the pairs without a fragment from surtr_pair_status (pair = (cell - cellBegin)
+// * pieces + piece, the order of the reference's double loop, Src/Surtr.cpp:1457-1504), the fragments from their status word.
+void FractureEngine::report_flagged(const std::vector<Fragment>& frags, uint32_t cellBegin, uint32_t cellEnd, const char* what)
+{
+    flagged_ = FlaggedUnits();
+    flagged_.n_failed = counts_.n_failed;
+    if (counts_.n_failed == 0) return;
+    for (size_t f = 0; f < frags.size(); ++f) if (frags[f].status != 0) flagged_.fragments.push_back((uint32_t)f);
+    const uint32_t n_pairs = (cellEnd - cellBegin) * n_pieces_;
+    std::vector<uint32_t> st(n_pairs);
+    if (n_pairs != 0 && surtr_pair_status(ctx_, n_pairs, st.data()) == SURTR_OK)
+        for (uint32_t p = 0; p < n_pairs; ++p)
+            if (st[p] != 0) flagged_.pairs.emplace_back((int)(cellBegin + p / n_pieces_), (int)(p % n_pieces_));
+    if (!allow_flagged_)
+        throw Error(SURTR_E_TOPOLOGY, std::string(what) + ": " + std::to_string(flagged_.pairs.size()) + " (cell, piece) pair(s) without a valid clip and " +
+                    std::to_string(flagged_.fragments.size()) + " fragment(s) flagged (input outside the reference's domain; AllowFlagged(true) returns the rest)");
 }
 
 std::vector<Fragment> FractureEngine::download_fragments(bool render)
@@ -679,6 +699,7 @@ std::vector<Compound> FractureEngine::DoFracture(const Compound& targetCompound,
     check(surtr_event_refit(ctx_), "surtr_event_refit");
     check(surtr_event_counts(ctx_, &counts_), "surtr_event_counts");
     const std::vector<Fragment> frags = download_fragments(false);
+    report_flagged(frags, 0, n_cells_, "DoFracture");
     const uint32_t n0 = (uint32_t)outside.size();
     if (np != n0 + frags.size()) throw Error(SURTR_E_STATE, "DoFracture: piece count of the regrouping does not match the event");
     std::vector<const Piece*> all;

@@ -13,6 +13,7 @@
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/surtr_hip.h"
@@ -228,11 +229,23 @@ public:
     std::vector<Compound> DoFracture(const Compound& targetCompound, float maxAxisScale, const FractureArgs& args,
                                      const std::vector<Vector3>& spherePointCloud, FractureTrace* trace = nullptr);
     surtr_counts LastCounts() const { return counts_; }
+    // The degenerate policy at this level (include/surtr_hip.h, surtr_counts::n_failed): where the reference leaves its own
+    // arrays the engine flags the unit instead of emulating what the reference's memory happens to hold -- a flagged (cell,
+    // piece) pair yields NO fragment, a flagged fragment keeps its un-refitted Convex / has no triangles.  A caller must not
+    // lose pieces without knowing: by default ApplyFracture / PrepareFracture / DoFracture THROW Error(SURTR_E_TOPOLOGY) when
+    // the event flagged anything (the reference's own signal on that path is `throw std::exception()`, Src/Poly.cpp:258);
+    // after AllowFlagged(true) they return what is valid and LastFlagged() names what was left out.
+    struct FlaggedUnits { uint32_t n_failed = 0; std::vector<std::pair<int, int>> pairs /* (cell, piece): no fragment */; std::vector<uint32_t> fragments /* output index */; };
+    void AllowFlagged(bool allow) { allow_flagged_ = allow; }
+    const FlaggedUnits& LastFlagged() const { return flagged_; }
     surtr_ctx* Raw() { return ctx_; }
 
 private:
     void check(int rc, const char* what);
     std::vector<Fragment> download_fragments(bool render);
+    void report_flagged(const std::vector<Fragment>& frags, uint32_t cellBegin, uint32_t cellEnd, const char* what);
+    bool allow_flagged_ = false;
+    FlaggedUnits flagged_;
     surtr_ctx* ctx_ = nullptr;
     uint32_t n_cells_ = 0, n_pieces_ = 0;
     surtr_counts counts_{};
