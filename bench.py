@@ -71,7 +71,7 @@ def kernel_build_id():
     """Hash of the sources of the clip kernels: ties profiles/traffic.json to the build it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("surtr_hip.hip", "clip_core.h", "surtr_ctx.h", "small_clip.h", "literal_clip.h", "wave_clip.h"):
+    for f in ("surtr_hip.hip", "clip_core.h", "surtr_ctx.h", "small_clip.h", "literal_clip.h", "wave_clip.h", "prep_sorted.h"):
         h.update(open(os.path.join(ROOT, "surtr_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

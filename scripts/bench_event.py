@@ -21,6 +21,7 @@ for _ in range(10):
     for k, v in eng.kernel_times().items():
         if v >= 0: acc.setdefault(k, []).append(v)
 q = eng.queue_stats()
-print("%s: event ms min %.3f median %.3f | record clipper took %d handed on %d | kernels (median ms) %s" % (os.environ.get("SURTR_LIB", "default"), ts[0], ts[len(ts) // 2],
-      int(q[88]), int(q[89]), {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
+tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("SURTR_")) or "default"
+print("%s: event ms min %.3f median %.3f | record clipper took %d handed on %d | record images %d (given up on: %d) | kernels (median ms) %s" % (tag, ts[0], ts[len(ts) // 2],
+      int(q[88]), int(q[89]), int(q[91]), int(q[93]), {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
 eng.close()

@@ -177,12 +177,16 @@ struct Topo
 struct Shared
 {
     float4 planes[SURTR_MAXF + 1];
-    float4 pmar[SURTR_MAXF + 1];      // per plane: ball-test margin = rad*x + y + z*(|px|+|py|+|pz|)
+    union {
+        float4 pmar[SURTR_MAXF + 1];  // per plane: ball-test margin = rad*x + y + z*(|px|+|py|+|pz|)
+        uint32_t pw[4 * (SURTR_MAXF + 1)];      // the same bytes as counters, once the sphere tests are done (prep_sorted.h)
+    };
     uint32_t hist[SURTR_MAXF + 1];    // after the pre-pass: dropped vertices still alive after plane k
     uint32_t zhist[SURTR_MAXF + 1];   // dropped vertices that lie in plane k while still alive
     uint32_t nzero[SURTR_MAXF + 1];   // vertices of the reduced solid that lie in plane k before any plane clips them (>0: general path)
     uint32_t wsum[2 * SURTR_NWAVE_WIDE];
     uint32_t flagBad, flagErr;
+    uint32_t deg7;                    // pre-pass: a kept vertex has more than seven ring entries (no 16-byte record holds it)
     uint32_t pf[3][8];                // per-plane flags, triple buffered: 0 cut, 1 keep, 2 in-plane, 3 dup, 4 pred, 5 live, 6 long
     uint32_t changed;
     uint32_t misc[8];
@@ -431,6 +435,101 @@ __device__ void collapse_serial(Topo<TT>& T, uint32_t n1)
     }
 }
 
+// A kept vertex: its ring entries are added to its 64-block's count; a ring too long for a narrow (8-bit) length is flagged.
+__device__ __forceinline__ void prepass_keep_deg(uint2* bblk, Shared& sh, uint32_t v, uint32_t deg)
+{
+    atomicAdd(&bblk[v >> SURTR_LSH].y, deg);
+    if (deg > InLds::MAXLEN / 2u) sh.flagBad = 1;
+    if (deg > 7u) sh.deg7 = 1;
+}
+
+// A2 of the pre-pass: the exact test, densely over the work list `needy` (v | fc << 24): a vertex is dropped iff every vertex
+// of every incident face has the same first clipping plane.  klist / kcount (optional, the sorted pre-pass of k_prep_pairs): the
+// kept vertices are appended as vertex | (first clipping plane | 0x80 when the vertex lies in an earlier plane) << 24;
+// sh.misc[5] = some kept vertex does.
+template <int NB>
+__device__ inline void prepass_exact(const SolidIn in, const uint32_t F, Shared& sh, unsigned long long* bmask, uint2* bblk,
+                                     const uint32_t* needy, const uint32_t nNeedy, uint32_t* klist = nullptr, uint32_t* kcount = nullptr)
+{
+    const uint32_t l = lane_id(), w = wave_id();
+    const uint32_t V = in.nv;
+    auto keep_deg = [&](uint32_t v, uint32_t deg) { prepass_keep_deg(bblk, sh, v, deg); };
+    // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
+#ifdef SURTR_STAMP
+    if (threadIdx.x == 0 && V > 10000u) atomicAdd(&g_stamp[47], (unsigned long long)nNeedy);
+#endif
+    for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += group_size())
+    {
+        const uint32_t i = i0 + l;
+        bool keep = false, drop = false, zero = false; uint32_t f = 0, v = 0;
+        if (i < nNeedy)
+        {
+            const uint32_t e = needy[i];
+            v = e & 0xFFFFFFu; f = e >> 24;
+            const uint32_t deg = in.llen[v];
+            const int32_t* r = in.nbr + in.loff[v];
+            auto same_fc = [&](float x, float y, float z) -> bool {
+                for (uint32_t k = 0; k < f; ++k)
+                    if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
+                return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
+            };
+            for (uint32_t j0 = 0; j0 < deg && !keep; j0 += NB)
+            {
+                int32_t u[NB]; float ux[NB], uy[NB], uz[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                {
+                    const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
+                    ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                    if (u[q] >= 0 && !same_fc(ux[q], uy[q], uz[q])) keep = true;
+            }
+            if (!keep && !(in.tri != nullptr && in.tri[v]))
+            {
+                // faces that are not triangles: walk every incident face loop
+                for (uint32_t j = 0; j < deg && !keep; ++j)
+                {
+                    int32_t prev = (int32_t)v, cur = r[j];
+                    uint32_t steps = 0;
+                    while (cur != (int32_t)v && steps++ < V)
+                    {
+                        if (!same_fc(in.pos[3 * cur], in.pos[3 * cur + 1], in.pos[3 * cur + 2])) { keep = true; break; }
+                        const int32_t nx = face_next_in(in.nbr + in.loff[cur], in.llen[cur], prev);
+                        prev = cur; cur = nx;
+                    }
+                }
+            }
+            drop = !keep;
+            if (keep)
+            {
+                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
+                keep_deg(v, deg);
+                if (klist != nullptr)
+                {
+                    const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+                    uint32_t z = 0;
+                    for (uint32_t k = 0; k < f; ++k) if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) z = 0x80u;
+                    klist[atomicAdd(kcount, 1u)] = v | ((f | z) << 24);
+                    if (z) sh.misc[5] = 1u;
+                }
+            }
+            else
+            {
+                // in-plane at an earlier plane while alive: it is no "kept" vertex there
+                const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+                for (uint32_t k = 0; k < f; ++k)
+                    if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) { zero = true; atomicAdd(&sh.zhist[k], 1u); }
+            }
+        }
+        (void)zero;
+        wave_hist_add(sh.hist, f, drop);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // The pre-pass has two halves, so that a kernel of its own can run the first one without a Topo:
 //   prepass_select  which vertices form the reduced solid (bit mask + per-block counts), hist/zhist; n vertices,
@@ -469,10 +568,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     const bool keepall = V <= SURTR_KEEPALL_V;
     for (uint32_t b = tid; b < nbV; b += group_size()) bblk[b] = make_uint2(0u, 0u);
     __syncthreads();
-    auto keep_deg = [&](uint32_t v, uint32_t deg) {
-        atomicAdd(&bblk[v >> SURTR_LSH].y, deg);
-        if (deg > InLds::MAXLEN / 2u) sh.flagBad = 1;
-    };
+    auto keep_deg = [&](uint32_t v, uint32_t deg) { prepass_keep_deg(bblk, sh, v, deg); };
     if (keepall)
     {
         for (uint32_t b = tid; b < nbV; b += group_size())
@@ -613,73 +709,7 @@ __device__ inline void prepass_select(const SolidIn in, const uint32_t F, Shared
     }
     __syncthreads();
     STAMP(0);
-    // ---- A2: the exact test, densely over the work list (neighbour loads batched: latency rules here) ----
-    const uint32_t nNeedy = sh.misc[3];
-#ifdef SURTR_STAMP
-    if (tid == 0 && V > 10000u) atomicAdd(&g_stamp[47], (unsigned long long)nNeedy);
-#endif
-    for (uint32_t i0 = w << SURTR_LSH; i0 < nNeedy; i0 += group_size())
-    {
-        const uint32_t i = i0 + l;
-        bool keep = false, drop = false, zero = false; uint32_t f = 0, v = 0;
-        if (i < nNeedy)
-        {
-            const uint32_t e = needy[i];
-            v = e & 0xFFFFFFu; f = e >> 24;
-            const uint32_t deg = in.llen[v];
-            const int32_t* r = in.nbr + in.loff[v];
-            auto same_fc = [&](float x, float y, float z) -> bool {
-                for (uint32_t k = 0; k < f; ++k)
-                    if (side_of(plane_dist(sh.planes[k], x, y, z)) < 0) return false;
-                return side_of(plane_dist(sh.planes[f], x, y, z)) < 0;
-            };
-            for (uint32_t j0 = 0; j0 < deg && !keep; j0 += NB)
-            {
-                int32_t u[NB]; float ux[NB], uy[NB], uz[NB];
-#pragma unroll
-                for (int q = 0; q < NB; ++q) u[q] = (j0 + q < deg) ? r[j0 + q] : -1;
-#pragma unroll
-                for (int q = 0; q < NB; ++q)
-                {
-                    const int32_t uu = u[q] < 0 ? (int32_t)v : u[q];
-                    ux[q] = in.pos[3 * uu]; uy[q] = in.pos[3 * uu + 1]; uz[q] = in.pos[3 * uu + 2];
-                }
-#pragma unroll
-                for (int q = 0; q < NB; ++q)
-                    if (u[q] >= 0 && !same_fc(ux[q], uy[q], uz[q])) keep = true;
-            }
-            if (!keep && !(in.tri != nullptr && in.tri[v]))
-            {
-                // faces that are not triangles: walk every incident face loop
-                for (uint32_t j = 0; j < deg && !keep; ++j)
-                {
-                    int32_t prev = (int32_t)v, cur = r[j];
-                    uint32_t steps = 0;
-                    while (cur != (int32_t)v && steps++ < V)
-                    {
-                        if (!same_fc(in.pos[3 * cur], in.pos[3 * cur + 1], in.pos[3 * cur + 2])) { keep = true; break; }
-                        const int32_t nx = face_next_in(in.nbr + in.loff[cur], in.llen[cur], prev);
-                        prev = cur; cur = nx;
-                    }
-                }
-            }
-            drop = !keep;
-            if (keep)
-            {
-                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-                keep_deg(v, deg);
-            }
-            else
-            {
-                // in-plane at an earlier plane while alive: it is no "kept" vertex there
-                const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
-                for (uint32_t k = 0; k < f; ++k)
-                    if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) { zero = true; atomicAdd(&sh.zhist[k], 1u); }
-            }
-        }
-        (void)zero;
-        wave_hist_add(sh.hist, f, drop);
-    }
+    prepass_exact<NB>(in, F, sh, bmask, bblk, needy, sh.misc[3]);
     }   // !keepall
     __syncthreads();
     STAMP(1);

@@ -203,6 +203,66 @@ __global__ void k_piece_spheres(uint32_t NB, uint32_t n, const uint32_t* __restr
     bsph[g] = make_float4(cx, cy, cz, (float)(R * 1.000001) + 1e-30f);
 }
 
+// A coarser level of spheres: sphere g of piece p holds SURTR_SPH_FAN consecutive spheres of the level below (bo / boc: first
+// sphere of every piece at the lower / this level).
+#ifndef SURTR_SPH_FAN
+#define SURTR_SPH_FAN 8u
+#endif
+__global__ void k_piece_spheres_up(uint32_t NBc, uint32_t n, const uint32_t* __restrict__ bo, const uint32_t* __restrict__ boc,
+                                   const float4* __restrict__ lower, float4* __restrict__ upper)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= NBc) return;
+    const uint32_t p = piece_of(boc, n, g), a = bo[p], m = bo[p + 1] - a;
+    const uint32_t i0 = (g - boc[p]) * SURTR_SPH_FAN, i1 = i0 + SURTR_SPH_FAN < m ? i0 + SURTR_SPH_FAN : m;
+    double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = i0; i < i1; ++i)
+    {
+        const float4 s = lower[a + i];
+        const double c[3] = {s.x, s.y, s.z};
+        for (int q = 0; q < 3; ++q) { blo[q] = c[q] - s.w < blo[q] ? c[q] - s.w : blo[q]; bhi[q] = c[q] + s.w > bhi[q] ? c[q] + s.w : bhi[q]; }
+    }
+    const float cx = (float)((blo[0] + bhi[0]) / 2), cy = (float)((blo[1] + bhi[1]) / 2), cz = (float)((blo[2] + bhi[2]) / 2);
+    double R = 0;
+    for (uint32_t i = i0; i < i1; ++i)
+    {
+        const float4 s = lower[a + i];
+        const double dx = s.x - (double)cx, dy = s.y - (double)cy, dz = s.z - (double)cz;
+        const double d = sqrt(dx * dx + dy * dy + dz * dz) + (double)s.w;
+        R = d > R ? d : R;
+    }
+    upper[g] = make_float4(cx, cy, cz, (float)(R * 1.000001) + 1e-30f);
+}
+
+// Rings in sorted space.  iperm: piece-local sorted index of every vertex; deg (-> loff_s by an exclusive sum); the entries.
+__global__ void k_piece_iperm(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm,
+                              const uint32_t* __restrict__ llen, uint32_t* __restrict__ iperm, uint32_t* __restrict__ deg)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > V) return;
+    if (i == V) { deg[V] = 0u; return; }
+    const uint32_t p = piece_of(vo, n, i), a = vo[p];
+    iperm[a + perm[i]] = i - a;
+    deg[i] = llen[a + perm[i]];
+}
+__global__ void k_piece_nbr_s(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm,
+                              const uint32_t* __restrict__ loff, const uint32_t* __restrict__ llen, const int32_t* __restrict__ nbr,
+                              const uint8_t* __restrict__ tri, const uint32_t* __restrict__ iperm, const uint32_t* __restrict__ loff_s,
+                              int32_t* __restrict__ nbr_s, uint2* __restrict__ hdr_s)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V) return;
+    const uint32_t p = piece_of(vo, n, i), a = vo[p], m = vo[p + 1] - a;
+    const uint32_t g = a + perm[i];
+    const uint32_t lo = loff[g], len = llen[g], so = loff_s[i];
+    for (uint32_t j = 0; j < len; ++j)
+    {
+        const int32_t u = nbr[lo + j];
+        nbr_s[so + j] = (u >= 0 && (uint32_t)u < m) ? (int32_t)iperm[a + (uint32_t)u] : -1;      // (an invalid link: the upload refuses the piece)
+    }
+    hdr_s[i] = make_uint2(so, len | (tri[g] ? 0u : 0x80000000u));
+}
+
 // Poly::Transform (Src/Poly.cpp:580-585): Position = XMVector3TransformCoord(Position, XMMatrixTranspose(matrix)).
 // XMVector3TransformCoord (DirectXMath, not in the reference tree): r = z*M.r[2] + M.r[3]; r = y*M.r[1] + r;
 // r = x*M.r[0] + r; result = r.xyz / r.w -- with M = the transpose, M.r[k][c] = world[4*c + k].
@@ -251,14 +311,20 @@ int pool_reserve(surtr_ctx* ctx, T** p, size_t& cap, size_t need)
     return SURTR_OK;
 }
 
+static inline uint32_t up_count(uint32_t m) { return (m + SURTR_SPH_FAN - 1u) / SURTR_SPH_FAN; }
+
 int reserve_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, uint32_t H, uint32_t NB)
 {
     int rc = 0;
 #define R(ptr, cap, need) do { rc = pool_reserve(ctx, &S.ptr, S.cap, (size_t)(need)); if (rc) return rc; } while (0)
     R(pos, c_pos, 3 * (size_t)V + 3); R(loff, c_loff, (size_t)V + 1); R(llen, c_llen, V); R(nbr, c_nbr, (size_t)H + 1); R(vo, c_vo, n + 1);
     R(tri, c_tri, V); R(rad, c_rad, V); R(perm, c_perm, V); R(posr_s, c_posr_s, (size_t)V + 1);
-    R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, V);
+    R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, (size_t)V + 1);
     R(dup, c_dup, n + 1);
+    // (every piece has at least one sphere per level: NB / 8 + n and NB / 64 + n bound the coarser levels)
+    R(iperm, c_iperm, V); R(loff_s, c_loff_s, (size_t)V + 1); R(nbr_s, c_nbr_s, (size_t)H + 1); R(hdr_s, c_hdr_s, (size_t)V + 1);
+    R(bsph2, c_bsph2, (size_t)NB / SURTR_SPH_FAN + n + 1); R(bo2, c_bo2, n + 1);
+    R(bsph3, c_bsph3, (size_t)NB / (SURTR_SPH_FAN * SURTR_SPH_FAN) + n + 1); R(bo3, c_bo3, n + 1);
 #undef R
     return SURTR_OK;
 }
@@ -285,6 +351,22 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
     if (hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp, tmp_bytes, S.key, S.key2, S.val, S.perm, (int)V, 0, end_bit, st) != hipSuccess) return SURTR_E_HIP;
     hipLaunchKernelGGL(k_piece_sorted, gridV, blk, 0, st, V, n, S.vo, S.pos, S.rad, S.perm, S.posr_s);
     if (NB) hipLaunchKernelGGL(k_piece_spheres, dim3((NB + 255) / 256), blk, 0, st, NB, n, S.vo, S.bo, S.posr_s, S.bsph);
+    // two coarser sphere levels for the hierarchical cull of the pre-pass
+    std::vector<uint32_t> bo2(n + 1, 0u), bo3(n + 1, 0u);
+    for (uint32_t p = 0; p < n; ++p) { bo2[p + 1] = bo2[p] + up_count(bo_h[p + 1] - bo_h[p]); bo3[p + 1] = bo3[p] + up_count(bo2[p + 1] - bo2[p]); }
+    HIPCHK(hipMemcpyAsync(S.bo2, bo2.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(S.bo3, bo3.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, st));
+    // (pageable source: staged before the call returns, like S.bo above)
+    if (bo2[n]) hipLaunchKernelGGL(k_piece_spheres_up, dim3((bo2[n] + 255) / 256), blk, 0, st, bo2[n], n, S.bo, S.bo2, S.bsph, S.bsph2);
+    if (bo3[n]) hipLaunchKernelGGL(k_piece_spheres_up, dim3((bo3[n] + 255) / 256), blk, 0, st, bo3[n], n, S.bo2, S.bo3, S.bsph2, S.bsph3);
+    // the rings in sorted space: degrees in sorted order (S.val is free after the sort) -> offsets -> entries
+    hipLaunchKernelGGL(k_piece_iperm, dim3((V + 256) / 256), blk, 0, st, V, n, S.vo, S.perm, S.llen, S.iperm, S.val);
+    tmp_bytes = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, S.val, S.loff_s, (int)V + 1, st) != hipSuccess) return SURTR_E_HIP;
+    rc = pool_reserve(ctx, &ctx->sort_tmp, ctx->c_sort_tmp, tmp_bytes + 16);
+    if (rc) return rc;
+    if (hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp, tmp_bytes, S.val, S.loff_s, (int)V + 1, st) != hipSuccess) return SURTR_E_HIP;
+    hipLaunchKernelGGL(k_piece_nbr_s, gridV, blk, 0, st, V, n, S.vo, S.perm, S.loff, S.llen, S.nbr, S.tri, S.iperm, S.loff_s, S.nbr_s, S.hdr_s);
     HIPCHK(hipGetLastError());
     return SURTR_OK;
 }

@@ -31,7 +31,8 @@ struct PairRec
 enum { IMG_NONE = 0,      // no image: k_clip_pairs runs the pre-pass itself
        IMG_NARROW = 1,    // 16-bit image, loads straight into the LDS topology
        IMG_WIDE = 2,      // the reduced solid does not fit the LDS topology: k_clip_pairs goes to global scratch directly
-       IMG_EMPTY = 3 };   // nothing of the Mesh is left
+       IMG_EMPTY = 3,     // nothing of the Mesh is left
+       IMG_REC = 4 };     // the band as sorted 16-byte records + positions (prep_sorted.h): the record clipper streams it as it is
 
 // Byte offsets of the sections of one image (all 16-byte aligned): hist/zhist/nzero (F words each), the keep mask
 // (one word per 64 input vertices), then the reduced solid in the LDS layout, then its positions.
@@ -53,7 +54,10 @@ struct PrepPool { char* base; size_t per_wg; uint32_t VMAX; };
 static size_t prep_bytes_per_wg(uint32_t VMAX)
 {
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8);
+    return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8) +
+           2 * r((size_t)VMAX + 64) +     // + first clipping planes by sorted index / by band index (prep_sorted.h)
+           2 * r((size_t)VMAX * 4) +      // + kept list, face-walk list
+           r((size_t)VMAX * 2 + 64);      // + vertex -> sorted id of the record emit
 }
 
 struct FragRec
@@ -89,6 +93,13 @@ struct Pieces
     // solid need not close, and where the reference's bounded walk stops then depends on its vertex count of the moment: these
     // solids take the literal clipper (literal_clip.h) from the start.
     const uint8_t* mdup; const uint8_t* cdup;
+    // the Mesh rings once more in SORTED space (round 4, pieces_dev.hip): sorted slot i (global over the set) has the header
+    // mhdr_s[i] = (first entry in mnbr_s, ring length | bit 31: some incident face is no triangle) and the ring
+    // mnbr_s[x .. x + length) whose entries are piece-local SORTED indices.  The pre-pass of k_prep_pairs looks the first
+    // clipping plane of a neighbour up by its sorted index.
+    // mbsph2 / mbsph3: one sphere per 8 / 64 of the SURTR_SB-vertex spheres (mbo2 / mbo3: first such sphere of every piece)
+    const uint2* mhdr_s; const int32_t* mnbr_s;
+    const float4* mbsph2; const uint32_t* mbo2; const float4* mbsph3; const uint32_t* mbo3;
 };
 
 struct ScratchPool
@@ -159,11 +170,15 @@ struct PieceSet
     uint32_t* perm = nullptr; float4* posr_s = nullptr; float4* bsph = nullptr; uint32_t* bo = nullptr;
     float* box = nullptr; unsigned long long* key = nullptr; unsigned long long* key2 = nullptr; uint32_t* val = nullptr;    // Morton sort
     uint8_t* dup = nullptr; size_t c_dup = 0;       // per piece: a ring lists a neighbour twice
+    // rings in sorted space + two coarser sphere levels (see Pieces)
+    uint32_t* iperm = nullptr; uint32_t* loff_s = nullptr; int32_t* nbr_s = nullptr; uint2* hdr_s = nullptr;
+    float4* bsph2 = nullptr; uint32_t* bo2 = nullptr; float4* bsph3 = nullptr; uint32_t* bo3 = nullptr;
+    size_t c_iperm = 0, c_loff_s = 0, c_nbr_s = 0, c_hdr_s = 0, c_bsph2 = 0, c_bo2 = 0, c_bsph3 = 0, c_bo3 = 0;
     size_t c_pos = 0, c_loff = 0, c_llen = 0, c_nbr = 0, c_vo = 0, c_tri = 0, c_rad = 0, c_perm = 0, c_posr_s = 0, c_bsph = 0,
            c_bo = 0, c_box = 0, c_key = 0, c_key2 = 0, c_val = 0;
     void release()
     {
-        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val, dup};
+        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val, dup, iperm, loff_s, nbr_s, hdr_s, bsph2, bo2, bsph3, bo3};
         for (void* p : all) if (p) (void)hipFree(p);
         *this = PieceSet();
     }

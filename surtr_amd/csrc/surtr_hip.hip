@@ -27,6 +27,7 @@
 #include "small_clip.h"
 #include "literal_clip.h"
 #include "wave_clip.h"
+#include "prep_sorted.h"
 
 // LDS-resident topology of one workgroup (Topo<InLds>) + the dispatcher that falls back to global scratch.
 template <uint32_t LV, uint32_t LH>
@@ -746,11 +747,13 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifndef SURTR_PREP_MINV
 #define SURTR_PREP_MINV 2048u      // smaller meshes are pre-passed by k_clip_pairs itself (measured on BASELINE configs[4])
 #endif
+#ifndef SURTR_PREP_NB
 #define SURTR_PREP_NB 1024u         // 64-vertex blocks whose masks fit this kernel's LDS (65536 vertices)
+#endif
 #ifndef SURTR_PREP_WAVES
 #define SURTR_PREP_WAVES 7       // workgroups per CU = waves per SIMD: the register budget is set for that (<= 72 VGPRs)
 #endif
-__device__ __attribute__((always_inline)) static inline void prep_pairs_body(Shared& sh, unsigned long long* lmask, uint2* lblk,
+__device__ __attribute__((always_inline)) static inline void prep_pairs_body(Shared& sh, unsigned long long* lmask, uint2* lblk, uint32_t rec_on,
                                                          const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
@@ -770,6 +773,11 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
     uint32_t* und = (uint32_t*)take((size_t)(pool.VMAX / SURTR_SB + 2) * 4);
     unsigned long long* gmask = (unsigned long long*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
+    uint8_t* vfc = (uint8_t*)take((size_t)pool.VMAX + 64);
+    uint8_t* fcb = (uint8_t*)take((size_t)pool.VMAX + 64);
+    uint32_t* klist = (uint32_t*)take((size_t)pool.VMAX * 4);
+    uint32_t* walks = (uint32_t*)take((size_t)pool.VMAX * 4);
+    uint16_t* sidmap = (uint16_t*)take((size_t)pool.VMAX * 2 + 64);      // all 0xFFFF between pairs (ensure_prep sets it, prepass_emit_records restores it)
 #ifdef SURTR_STAMP
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
     unsigned long long wg_work = 0;
@@ -826,7 +834,15 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
 #define SURTR_PREP_G 1           // occupancy hides the gather latency here, not unrolling
 #define SURTR_PREP_NBATCH 4
 #endif
-        prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
+        // a piece with a sorted copy whose groups fit the LDS table: selection by sphere hierarchy and fc look-ups (prep_sorted.h)
+        constexpr uint32_t kUbWords = (SURTR_PREP_NB - SURTR_PS_NB) * 2u;      // the tail of lblk as 32-bit words: one bit per group
+        const bool sorted_sel = !(rec_on & 2u) && nbV <= SURTR_PS_NB && (V + SURTR_SB - 1u) / SURTR_SB <= 32u * kUbWords && V < (1u << 24) && P.mhdr_s != nullptr;
+        if (sorted_sel)
+        {
+            const SortedRings sr{P.mhdr_s + m0, P.mnbr_s, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
+            prepass_select_sorted(min, sr, F, sh, lmask, lblk, (uint32_t*)(lblk + SURTR_PS_NB), kUbWords, vfc, needy, und, klist, walks, n, hsum);
+        }
+        else prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
         __syncthreads();
         STAMP(71);
@@ -835,10 +851,32 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
         // room for the cut points behind the positions, for the topology of the kernel that will take the pair
         const bool to_half = half_on && fits_half(n, hsum, capVs);
+        // The band goes out as a record image when the record clipper will take the pair as it is: a regular band (no vertex in a
+        // plane before its first clipping plane, rings of at most seven entries, no sliver piece), of a size the id map and the
+        // record ids hold, of a cost class a record kernel serves (the whole-CU kernel only when it runs: big_quota all ones).
+        const bool rec_fmt = (rec_on & 1u) != 0u && sorted_sel && fmt == IMG_NARROW && !to_half && F <= WC_MAXF && n < WC_MAXN && n <= (rec_on >> 8) &&
+                             sh.misc[5] == 0u && sh.deg7 == 0u && P.mdup[piece] == 0 &&
+                             (fits_with_room(n, hsum, capV, SURTR_LH) || big_quota == 0xFFFFFFFFu);
+        uint32_t ncut_rec = 0;
+        if (rec_fmt)
+        {
+            const RecLayout rl = rec_layout(F, n);
+            const uint32_t need16 = rl.total / 16u;
+            if (tid == 0) sh.misc[0] = atomicAdd(&A.cursors[10], need16);
+            __syncthreads();
+            off16 = sh.misc[0];
+            __syncthreads();
+            if ((uint64_t)off16 + need16 > IA.cap16) fmt = IMG_NONE;      // arena full: the clip kernel does this pair alone
+            else
+            {
+                prepass_emit_records(min, F, sh, bmask, bblk, klist, orig, fcb, sidmap, sh.pw, IA.base + (size_t)off16 * 16u, n, ncut_rec);
+                fmt = IMG_REC;
+            }
+        }
         // (none for the half-size kernel: it works on a copy, so that its retry list finds the image as it was)
         const uint32_t posCap = to_half ? 0u : (fits_with_room(n, hsum, capV, SURTR_LH) ? capV : 2u * capV);
         const ImgLayout lay = img_layout(F, nbV, n, hsum, posCap);
-        if (fmt == IMG_NARROW)
+        if (fmt == IMG_NARROW && !rec_fmt)
         {
             const uint32_t need16 = lay.total / 16u;
             if (tid == 0) sh.misc[0] = atomicAdd(&A.cursors[10], need16);
@@ -861,7 +899,9 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             T.capV = n; T.capH = hsum; T.nS = T.nLive = T.hUsed = 0; T.kcur = T.n0cur = 0; T.zmode = false;
             if (tid < 4u) sh.cutmask[tid] = 0u;
             __syncthreads();
-            prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);      // also counts sh.nzero, collects sh.cutmask
+            // (also counts sh.nzero, collects sh.cutmask)
+            if (sorted_sel) prepass_emit_klist(min, F, sh, T, bmask, bblk, klist, orig, (uint2*)und, n, hsum);
+            else prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);
             STAMP(74);
             prepass_finish_hist(F, sh);
             uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* nz = (uint32_t*)(img + lay.nzero);
@@ -871,22 +911,24 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         if (tid == 0)
         {
             pairs[p].img_fmt = fmt; pairs[p].img_off = off16; pairs[p].img_n = n; pairs[p].img_h = hsum; pairs[p].img_pc = posCap;
+            if (fmt == IMG_REC) atomicAdd(&A.cursors[91], 1u);      // (diagnostic: surtr_queue_stats)
+            if (sorted_sel) atomicAdd(&A.cursors[92], 1u);
             // classes 14 and 15 go to k_clip_pairs_big: bands that leave the regular LDS topology little room to grow
             // (the first plane alone may add a thousand vertices), and solids beyond any LDS topology
             // solids of at most half the half-size topology have their own table (k_clip_pairs_half)
             uint32_t cls = 15u;
             if (fmt == IMG_NONE) cls = 13u;
-            else if (fmt == IMG_NARROW)
+            else if (fmt == IMG_NARROW || fmt == IMG_REC)
             {
                 // cost of the clip = cutting planes x ~41 000 cycles + load / islands / copy ~25 cycles per vertex, in units of
                 // 110 000 cycles; the planes that clip an original vertex of the band are a lower bound of the cutting planes
-                const uint32_t ncut = (uint32_t)(__builtin_popcount(sh.cutmask[0]) + __builtin_popcount(sh.cutmask[1]) +
+                const uint32_t ncut = fmt == IMG_REC ? ncut_rec : (uint32_t)(__builtin_popcount(sh.cutmask[0]) + __builtin_popcount(sh.cutmask[1]) +
                                                  __builtin_popcount(sh.cutmask[2]) + __builtin_popcount(sh.cutmask[3]));
                 const uint32_t cost = (41u * ncut + n / 40u) / 110u;
                 cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (cost < 11u ? cost : 11u);
                 // a band vertex lies in a plane: the record clipper hands the pair to the general clipper, which takes longer --
                 // such pairs go first (the top regular class), not into the tail of the queue
-                if (cls < 12u) { bool inplane = false; for (uint32_t k = 0; k < F; ++k) if (sh.nzero[k] != 0u) inplane = true; if (inplane) cls = 12u; }
+                if (cls < 12u && fmt == IMG_NARROW) { bool inplane = false; for (uint32_t k = 0; k < F; ++k) if (sh.nzero[k] != 0u) inplane = true; if (inplane) cls = 12u; }
             }
             // k_clip_pairs_big has a few dozen workgroups: on a mesh whose bands outgrow the regular topology as a rule (some
             // 100 000 vertices) it takes the first `big_quota` such pairs and the regular kernel's workgroups do the others on
@@ -895,14 +937,14 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             // fewer than WC_MAXN vertices; the others are spread over the regular kernel's workgroups as before)
             if (big_quota == 0xFFFFFFFFu)
             {
-                if (cls >= 14u && !(fmt == IMG_NARROW && n < WC_MAXN)) cls = 13u;
+                if (cls >= 14u && !((fmt == IMG_NARROW || fmt == IMG_REC) && n < WC_MAXN)) cls = 13u;
                 // ... and a band of more than big_n vertices that the general clipper's topology would still hold: its first planes
                 // clip thousands of vertices at once, more than the regular record clipper's 56 KB take (it would hand the pair on
                 // after the loader and a plane or two) -- the whole-CU variant has the room
-                else if (cls < 12u && fmt == IMG_NARROW && n > big_n && n < WC_MAXN) cls = 14u;
+                else if (cls < 12u && (fmt == IMG_NARROW || fmt == IMG_REC) && n > big_n && n < WC_MAXN) cls = 14u;
             }
             else if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
-            if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);
+            if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);      // (a record image is never to_half)
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
 #ifdef SURTR_STAMP
@@ -919,12 +961,12 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -935,12 +977,12 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lmask[SURTR_PREP_NB];
     __shared__ uint2 lblk[SURTR_PREP_NB];
-    prep_pairs_body(sh, lmask, lblk, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -1099,6 +1141,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_body(Sha
         PairRec rec = pairs[p];
         if (rec.cv_n == 0 || rec.status != 0) continue;       // empty Convex: the Mesh is not clipped (:1467-1468)
         if (rec.img_fmt == IMG_EMPTY) continue;               // the pre-pass kernel found nothing left of the Mesh
+        if (rec.img_fmt == IMG_REC) rec.img_fmt = IMG_NONE;   // (a record image is no input of the general clipper: never queued here)
 #ifdef SURTR_STAMP
         const unsigned long long pair_t0 = __builtin_readcyclecounter();
         if (tid == 0) for (int q = 0; q < 16; ++q) sh.ph[q] = 0;
@@ -1201,16 +1244,12 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         int err = WC_BAIL;
-        if (rec.img_fmt == IMG_NARROW && P.mdup[piece] == 0 && F <= WC_MAXF)
+        if ((rec.img_fmt == IMG_NARROW || rec.img_fmt == IMG_REC) && P.mdup[piece] == 0 && F <= WC_MAXF)
         {
             for (uint32_t k = tid; k < F; k += group_size()) W.planes[k] = planes[f0 + k];
             const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
             const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
-            const char* img = IA.base + (size_t)rec.img_off * 16u;
-            const ImgLayout lay = img_layout(F, nbV, rec.img_n, rec.img_h);
-            const WcImg im{(const uint16_t*)(img + lay.loff), (const uint8_t*)(img + lay.llen), (const uint8_t*)(img + lay.comp),
-                           (const uint16_t*)(img + lay.ring), (const float*)(img + lay.pos), (const uint32_t*)(img + lay.hist),
-                           (const uint32_t*)(img + lay.zhist), (const uint32_t*)(img + lay.nzero), rec.img_n, rec.img_h};
+            char* img = IA.base + (size_t)rec.img_off * 16u;
             unsigned long long zmask = 0ull;
             WcOut o{0u, 0u, 0u, 0u};
             WcCtr ctr{0u, 0u};
@@ -1218,8 +1257,25 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
             if (tid == 0) for (int q = 0; q < 32; ++q) W.ph[q] = 0ull;
 #endif
             bool fits = false;
-            const WcGlob g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WL::kNR, fits);
-            if (fits) err = wc_load(W, im, F, g, zmask, ctr, A.cursors + 96);
+            WcGlob g;
+            if (rec.img_fmt == IMG_REC)
+            {
+                // the band is there as the record clipper streams it (k_prep_pairs, prep_sorted.h): copied into this workgroup's
+                // scratch slot, no sort
+                const RecLayout rl = rec_layout(F, rec.img_n);
+                g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WL::kNR, fits);
+                if (fits) err = wc_attach(W, (const uint32_t*)(img + rl.hist), (const uint32_t*)(img + rl.zhist), (const uint32_t*)(img + rl.bst), F, rec.img_n,
+                                          (const WcW4*)(img + rl.grec), (const float4*)(img + rl.gpos), g, zmask, ctr, A.cursors + 96);
+            }
+            else
+            {
+                const ImgLayout lay = img_layout(F, nbV, rec.img_n, rec.img_h);
+                const WcImg im{(const uint16_t*)(img + lay.loff), (const uint8_t*)(img + lay.llen), (const uint8_t*)(img + lay.comp),
+                               (const uint16_t*)(img + lay.ring), (const float*)(img + lay.pos), (const uint32_t*)(img + lay.hist),
+                               (const uint32_t*)(img + lay.zhist), (const uint32_t*)(img + lay.nzero), rec.img_n, rec.img_h};
+                g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WL::kNR, fits);
+                if (fits) err = wc_load(W, im, F, g, zmask, ctr, A.cursors + 96);
+            }
             if (err == 0) err = wc_planes(W, F, rec.img_n, V - rec.img_n, zmask, g, 2u * WL::kNR, o, ctr, A.cursors + 96, walk0);
             if (err == 0 && o.nLive != 0u) err = wc_park(W, F, rec.img_n, o, g, A, rec, ctr, A.cursors + 96);
 #ifdef SURTR_STAMP
@@ -1236,6 +1292,9 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
                 }
             }
 #endif
+            // the general clipper has no use for a record image: for a pair the record clipper gives up on it starts from the piece
+            // (its own pre-pass), as for a pair that never had an image
+            if (err == WC_BAIL && rec.img_fmt == IMG_REC) { rec.img_fmt = IMG_NONE; if (tid == 0) atomicAdd(&A.cursors[93], 1u); }
         }
         if (tid == 0) atomicAdd(&A.cursors[err == WC_BAIL ? 89 : 88], 1u);       // (diagnostic: pairs the record clipper took / handed on)
         if (err == WC_BAIL)
@@ -2997,6 +3056,8 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
         free_dev(ctx->prep.base); ctx->prep.base = nullptr;
         ctx->prep.VMAX = VMAX; ctx->prep.per_wg = prep_bytes_per_wg(VMAX); ctx->n_wg_prep = n_wg;
         HIPCHK(hipMalloc((void**)&ctx->prep.base, ctx->prep.per_wg * n_wg));
+        // the vertex -> sorted id map of the record emit is all ones between pairs (the rest of the scratch is written before it is read)
+        HIPCHK(hipMemsetAsync(ctx->prep.base, 0xFF, ctx->prep.per_wg * n_wg, ctx->stream));
     }
     if (ctx->cap_order < n_pairs)
     {
@@ -3097,6 +3158,9 @@ static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pai
 #ifndef SURTR_WAVE_BIG_N
 #define SURTR_WAVE_BIG_N 2800u
 #endif
+#ifndef SURTR_REC_MAXN
+#define SURTR_REC_MAXN 2304u
+#endif
 static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
     (void)hipSetDevice(ctx->device);
@@ -3131,7 +3195,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     }
     const PieceSet& M = ctx->mset; const PieceSet& C = ctx->cset;
     Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.posr_s, M.bsph, M.bo,
-             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces, M.dup, C.dup};
+             C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces, M.dup, C.dup,
+             M.hdr_s, M.nbr_s, M.bsph2, M.bo2, M.bsph3, M.bo3};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     const uint32_t* d_pair_order = nullptr;
     if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it
@@ -3164,6 +3229,18 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // (there nearly every band is beyond it and the regular kernel runs dry): applied below 180 000 vertices
     uint32_t big_n = (ctx->wave_big && ctx->vmax < 180000u) ? SURTR_WAVE_BIG_N : 0xFFFFFFFFu;
     if (const char* e = getenv("SURTR_WAVE_BIG_N")) big_n = (uint32_t)atoi(e);
+    // the regular pairs through the record clipper (wave_clip.h) once the pairs queue up; k_prep_pairs then leaves their bands as
+    // record images (rec_on)
+    bool wave_on = n_pairs > 3u * max_wg;
+    if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
+    uint32_t rec_on = wave_on ? 1u : 0u;
+    if (const char* e = getenv("SURTR_REC")) rec_on = (wave_on && atoi(e) != 0) ? 1u : 0u;      // (tests / A-B: 0 = images + wc_load as in round 3)
+    if (const char* e = getenv("SURTR_PREP_SORTED")) { if (atoi(e) == 0) rec_on = 2u; }             // (tests / A-B: 0 = round 3's selection, prepass_select)
+    // bands beyond this size keep the old image: they are the ones the record clipper runs out of room on, and a pair it gives up
+    // on is then finished in place from that image instead of from the piece
+    uint32_t rec_maxn = SURTR_REC_MAXN;
+    if (const char* e = getenv("SURTR_REC_MAXN")) rec_maxn = (uint32_t)atoi(e);
+    rec_on |= (rec_maxn < 0xFFFFFFu ? rec_maxn : 0xFFFFFFu) << 8;
     PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
     uint32_t wide_max = 4u * ctx->max_wg;
@@ -3172,11 +3249,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
@@ -3198,8 +3275,6 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // (measured on blocks of configs[3]: the record clipper wins once the pairs queue up -- 4 096 pairs 1.88 -> 1.65 ms, 2 048 pairs
     // 2.35 -> 2.30 ms for the event -- and loses when every pair has a workgroup to itself: 1 024 pairs 1.63 -> 1.69 ms, 512 pairs
     // 1.33 -> 1.45 ms; its loader sorts the band, which the general clipper's image copy does not have to)
-    bool wave_on = n_pairs > 3u * max_wg;
-    if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
     PROF_BEGIN_ON(11, st2);
     if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st2);
     if (n_pairs && wave_on)

@@ -16,6 +16,10 @@
 #define SURTR_KEEPALL_V 12u
 #endif
 #define SURTR_PREP_MINV 48u
+// one vertex per "64-block" and per sphere group here: the LDS tables of k_prep_pairs (static arrays in this build) are sized so
+// that the test meshes take the same paths as 50 000-vertex pieces do on the device
+#define SURTR_PREP_NB 65536u
+#define SURTR_PS_NB 57344u
 #define SURTR_SMALL_LV 64
 #define SURTR_SMALL_LH 512
 #include <cstdio>
