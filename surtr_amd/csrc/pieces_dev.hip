@@ -234,33 +234,38 @@ __global__ void k_piece_spheres_up(uint32_t NBc, uint32_t n, const uint32_t* __r
     upper[g] = make_float4(cx, cy, cz, (float)(R * 1.000001) + 1e-30f);
 }
 
-// Rings in sorted space.  iperm: piece-local sorted index of every vertex; deg (-> loff_s by an exclusive sum); the entries.
-__global__ void k_piece_iperm(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm,
-                              const uint32_t* __restrict__ llen, uint32_t* __restrict__ iperm, uint32_t* __restrict__ deg)
+// Rings in sorted space.  iperm: piece-local sorted index of every vertex; row_s: see Pieces.
+__global__ void k_piece_iperm(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm, uint32_t* __restrict__ iperm)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > V) return;
-    if (i == V) { deg[V] = 0u; return; }
+    if (i >= V) return;
     const uint32_t p = piece_of(vo, n, i), a = vo[p];
     iperm[a + perm[i]] = i - a;
-    deg[i] = llen[a + perm[i]];
 }
-__global__ void k_piece_nbr_s(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm,
+__global__ void k_piece_row_s(uint32_t V, uint32_t n, const uint32_t* __restrict__ vo, const uint32_t* __restrict__ perm,
                               const uint32_t* __restrict__ loff, const uint32_t* __restrict__ llen, const int32_t* __restrict__ nbr,
-                              const uint8_t* __restrict__ tri, const uint32_t* __restrict__ iperm, const uint32_t* __restrict__ loff_s,
-                              int32_t* __restrict__ nbr_s, uint2* __restrict__ hdr_s)
+                              const uint8_t* __restrict__ tri, const uint32_t* __restrict__ iperm, SRow* __restrict__ row_s)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= V) return;
     const uint32_t p = piece_of(vo, n, i), a = vo[p], m = vo[p + 1] - a;
     const uint32_t g = a + perm[i];
-    const uint32_t lo = loff[g], len = llen[g], so = loff_s[i];
-    for (uint32_t j = 0; j < len; ++j)
+    const uint32_t lo = loff[g], len = llen[g];
+    uint32_t h[8];
+    h[0] = (len <= 7u ? len : 0x40u) | (tri[g] ? 0u : 0x80u);
+    for (uint32_t j = 0; j < 7u; ++j)
     {
-        const int32_t u = nbr[lo + j];
-        nbr_s[so + j] = (u >= 0 && (uint32_t)u < m) ? (int32_t)iperm[a + (uint32_t)u] : -1;      // (an invalid link: the upload refuses the piece)
+        uint32_t e = 0xFFFFu;
+        if (len <= 7u && j < len)
+        {
+            const int32_t u = nbr[lo + j];
+            if (u >= 0 && (uint32_t)u < m) { const uint32_t x = iperm[a + (uint32_t)u]; e = x < 0xFFFFu ? x : 0xFFFFu; }      // (an invalid link: the upload refuses the piece)
+        }
+        h[1u + j] = e;
     }
-    hdr_s[i] = make_uint2(so, len | (tri[g] ? 0u : 0x80000000u));
+    SRow r;
+    for (int q = 0; q < 4; ++q) r.w[q] = h[2 * q] | (h[2 * q + 1] << 16);
+    row_s[i] = r;
 }
 
 // Poly::Transform (Src/Poly.cpp:580-585): Position = XMVector3TransformCoord(Position, XMMatrixTranspose(matrix)).
@@ -319,10 +324,10 @@ int reserve_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, uint32_t H,
 #define R(ptr, cap, need) do { rc = pool_reserve(ctx, &S.ptr, S.cap, (size_t)(need)); if (rc) return rc; } while (0)
     R(pos, c_pos, 3 * (size_t)V + 3); R(loff, c_loff, (size_t)V + 1); R(llen, c_llen, V); R(nbr, c_nbr, (size_t)H + 1); R(vo, c_vo, n + 1);
     R(tri, c_tri, V); R(rad, c_rad, V); R(perm, c_perm, V); R(posr_s, c_posr_s, (size_t)V + 1);
-    R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, (size_t)V + 1);
+    R(bsph, c_bsph, NB + 1); R(bo, c_bo, n + 1); R(box, c_box, 6 * (size_t)n); R(key, c_key, V); R(key2, c_key2, V); R(val, c_val, V);
     R(dup, c_dup, n + 1);
     // (every piece has at least one sphere per level: NB / 8 + n and NB / 64 + n bound the coarser levels)
-    R(iperm, c_iperm, V); R(loff_s, c_loff_s, (size_t)V + 1); R(nbr_s, c_nbr_s, (size_t)H + 1); R(hdr_s, c_hdr_s, (size_t)V + 1);
+    R(iperm, c_iperm, V); R(row_s, c_row_s, (size_t)V + 1);
     R(bsph2, c_bsph2, (size_t)NB / SURTR_SPH_FAN + n + 1); R(bo2, c_bo2, n + 1);
     R(bsph3, c_bsph3, (size_t)NB / (SURTR_SPH_FAN * SURTR_SPH_FAN) + n + 1); R(bo3, c_bo3, n + 1);
 #undef R
@@ -359,14 +364,9 @@ int derive_set(surtr_ctx* ctx, PieceSet& S, uint32_t n, uint32_t V, const std::v
     // (pageable source: staged before the call returns, like S.bo above)
     if (bo2[n]) hipLaunchKernelGGL(k_piece_spheres_up, dim3((bo2[n] + 255) / 256), blk, 0, st, bo2[n], n, S.bo, S.bo2, S.bsph, S.bsph2);
     if (bo3[n]) hipLaunchKernelGGL(k_piece_spheres_up, dim3((bo3[n] + 255) / 256), blk, 0, st, bo3[n], n, S.bo2, S.bo3, S.bsph2, S.bsph3);
-    // the rings in sorted space: degrees in sorted order (S.val is free after the sort) -> offsets -> entries
-    hipLaunchKernelGGL(k_piece_iperm, dim3((V + 256) / 256), blk, 0, st, V, n, S.vo, S.perm, S.llen, S.iperm, S.val);
-    tmp_bytes = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, S.val, S.loff_s, (int)V + 1, st) != hipSuccess) return SURTR_E_HIP;
-    rc = pool_reserve(ctx, &ctx->sort_tmp, ctx->c_sort_tmp, tmp_bytes + 16);
-    if (rc) return rc;
-    if (hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp, tmp_bytes, S.val, S.loff_s, (int)V + 1, st) != hipSuccess) return SURTR_E_HIP;
-    hipLaunchKernelGGL(k_piece_nbr_s, gridV, blk, 0, st, V, n, S.vo, S.perm, S.loff, S.llen, S.nbr, S.tri, S.iperm, S.loff_s, S.nbr_s, S.hdr_s);
+    // the rings in sorted space
+    hipLaunchKernelGGL(k_piece_iperm, gridV, blk, 0, st, V, n, S.vo, S.perm, S.iperm);
+    hipLaunchKernelGGL(k_piece_row_s, gridV, blk, 0, st, V, n, S.vo, S.perm, S.loff, S.llen, S.nbr, S.tri, S.iperm, S.row_s);
     HIPCHK(hipGetLastError());
     return SURTR_OK;
 }

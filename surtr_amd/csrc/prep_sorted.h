@@ -38,7 +38,7 @@ namespace surtr {
 
 struct SortedRings
 {
-    const uint2* hdr_s; const int32_t* nbr_s;
+    const SRow* row_s; const uint32_t* iperm;
     const float4* bsph2; const float4* bsph3;
 };
 
@@ -70,16 +70,30 @@ __device__ __forceinline__ void ps_append(uint32_t* list, uint32_t* counter, boo
     if (on) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull))] = value;
 }
 
-// Selection.  bmask / bblk: LDS, one word / pair per 64 vertices; ub: LDS, one bit per group ("undecided"), ubWords words;
-// vfc: global bytes by sorted index; needy, und, klist, walks: global work lists (V words each at most; und: one per group).
-// Requires in.nv < 2^24, ceil(in.nv / SURTR_SB) <= 32 * ubWords, ceil(in.nv / 64 / SURTR_SB) + 16 + ... 16-bit list entries in
-// bblk (the caller's SURTR_PS_NB rule), the sorted copy.
-// Leaves: the kept vertices as bits of bmask AND as klist[0 .. n) = vertex | (fc | 0x80: in a plane before fc) << 24, in no order;
-// bblk scanned (x: kept vertices before the block, y: their ring entries); sh.hist / zhist raw (prepass_finish_hist);
-// sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7.
+__device__ __forceinline__ void ps_append2(uint2* list, uint32_t* counter, bool on, uint2 value)
+{
+    const unsigned long long m = __ballot(on);
+    if (!m) return;
+    const uint32_t l = lane_id();
+    uint32_t base = 0;
+    if (l == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = lane_bcast(base, (uint32_t)__builtin_ctzll(m));
+    if (on) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull))] = value;
+}
+
+// Selection.  bmask / bblk: LDS, one word / pair per 64 vertices; ub: LDS, one bit per group ("undecided"), ubWords words
+// (ubWords <= the entries of bblk: bblk[q].x holds the set bits before word q until the kept vertices are counted);
+// vfc: global bytes, DENSE: the vertices of the undecided groups in ascending group order (a table by vertex would be written and
+// read a few bytes per cache line: 0.7 GB per configs[3] event, measured); needy, und, klist, walks: global work lists
+// (V entries each at most; und: one per group).
+// Requires in.nv < 65535, ceil(in.nv / SURTR_SB) <= 32 * ubWords, room for the 16-bit lists of A0 in bblk (the caller's
+// SURTR_PS_NB rule), the sorted copy.
+// Leaves: the kept vertices as bits of bmask AND as klist[0 .. n) = (vertex | (fc | 0x80: in a plane before fc) << 24, sorted
+// index), in no order; bblk scanned (x: kept vertices before the block, y: their ring entries); sh.hist / zhist raw
+// (prepass_finish_hist); sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7.
 __device__ __attribute__((always_inline)) inline void prepass_select_sorted(const SolidIn in, const SortedRings sr, const uint32_t F, Shared& sh,
                                                                             unsigned long long* bmask, uint2* bblk, uint32_t* ub, const uint32_t ubWords,
-                                                                            uint8_t* vfc, uint32_t* needy, uint32_t* und, uint32_t* klist, uint32_t* walks,
+                                                                            uint8_t* vfc, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
                                                                             uint32_t& n_out, uint32_t& hsum_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
@@ -159,6 +173,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
             if (q < ubWords)
             {
                 uint32_t at = carry + woff + inc - c;
+                bblk[q].x = at;
                 for (uint32_t m = ub[q]; m; m &= m - 1u) und[at++] = 32u * q + (uint32_t)__builtin_ctz(m);
             }
             carry += tot;
@@ -200,7 +215,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
             f = (live & cut) ? k : f;
             done = done | cut;
         }
-        if (valid) vfc[i] = (uint8_t)(f | z);
+        if (valid) vfc[sub * SURTR_SB + (l % SURTR_SB)] = (uint8_t)(f | z);
         const bool never = valid && f == PS_NEVER;
         const bool drop = valid && !never && clear;          // (|s| > margin at every plane up to fc: in no plane either)
         const bool need = valid && !never && !clear;
@@ -216,7 +231,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
                 prepass_keep_deg(bblk, sh, v, in.llen[v]);
                 if (z) sh.misc[5] = 1u;
             }
-            ps_append(klist, &sh.misc[6], never, v | ((f | z) << 24));
+            ps_append2(klist, &sh.misc[6], never, make_uint2(v | ((f | z) << 24), i));
         }
     }
     __syncthreads();
@@ -234,28 +249,29 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         const bool valid = t < nNeedy;
         const uint32_t e = valid ? needy[t] : 0u;
         const uint32_t i = e & 0xFFFFFFu, byte = e >> 24, f = byte & 0x7Fu;
-        const uint2 hd = sr.hdr_s[i];
-        const uint32_t lo = hd.x, deg = valid ? (hd.y & 0x7FFFFFFFu) : 0u, notri = hd.y >> 31;
-        bool differ = false;
-        for (uint32_t j0 = 0; j0 < deg; j0 += 8u)
+        const SRow row = sr.row_s[i];
+        const uint32_t hd = row.w[0] & 0xFFFFu;
+        const uint32_t deg = valid ? (hd & 7u) : 0u, notri = (hd >> 7) & 1u, big = (hd >> 6) & 1u;
+        // the first clipping plane of every neighbour in an undecided group: its byte sits at (rank of the group) * SB + place
+        uint32_t uq[7], on[7], fq[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
         {
-            int32_t u[8]; uint32_t ug[8], fq[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) u[q] = (j0 + (uint32_t)q < deg) ? sr.nbr_s[lo + j0 + (uint32_t)q] : -1;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-            {
-                const uint32_t g = (uint32_t)(u[q] < 0 ? 0 : u[q]) / SURTR_SB;
-                ug[q] = (u[q] >= 0 ? 1u : 0u) & ((ub[g >> 5] >> (g & 31u)) & 1u);
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) fq[q] = ug[q] ? ((uint32_t)vfc[(uint32_t)u[q]] & 0x7Fu) : f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) differ = differ | (fq[q] != f);
-            if (differ) break;
+            const uint32_t x = row.w[(q + 1) >> 1];
+            uq[q] = ((q + 1) & 1) ? (x >> 16) : (x & 0xFFFFu);
+            const uint32_t u = (uint32_t)q < deg ? uq[q] : 0u;
+            const uint32_t g = u / SURTR_SB, word = ub[g >> 5], bit = g & 31u;
+            on[q] = ((uint32_t)q < deg ? 1u : 0u) & ((word >> bit) & 1u);
+            uq[q] = (bblk[g >> 5].x + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))) * SURTR_SB + u % SURTR_SB;
         }
-        const bool walk = valid && notri != 0u && !differ;          // all neighbours agree, but the faces are larger than the 1-ring
-        const bool keep = valid && differ, drop = valid && !differ && !walk;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) fq[q] = on[q] ? ((uint32_t)vfc[uq[q]] & 0x7Fu) : f;
+        bool differ = false;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) differ = differ | (fq[q] != f);
+        // all neighbours agree but the faces are larger than the 1-ring, or the ring is not in the row: the exact test with face walks
+        const bool walk = valid && (big != 0u || (notri != 0u && !differ));
+        const bool keep = valid && differ && !walk, drop = valid && !differ && !walk;
         if (__ballot(keep | walk))
         {
             const uint32_t v = (keep | walk) ? in.perm[i] : 0u;
@@ -265,7 +281,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
                 prepass_keep_deg(bblk, sh, v, deg);
                 if (byte & 0x80u) sh.misc[5] = 1u;
             }
-            ps_append(klist, &sh.misc[6], keep, v | (byte << 24));
+            ps_append2(klist, &sh.misc[6], keep, make_uint2(v | (byte << 24), i));
             ps_append(walks, &sh.misc[0], walk, v | (f << 24));
         }
         wave_hist_add(sh.hist, f, drop);
@@ -278,7 +294,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         }
     }
     __syncthreads();
-    if (sh.misc[0] != 0u) prepass_exact<4>(in, F, sh, bmask, bblk, walks, sh.misc[0], klist, &sh.misc[6]);
+    if (sh.misc[0] != 0u) prepass_exact<4>(in, F, sh, bmask, bblk, walks, sh.misc[0], klist, &sh.misc[6], sr.iperm);
     __syncthreads();
     STAMP(1);
     for (uint32_t b = tid; b < nbV; b += G) bblk[b].x = (uint32_t)__builtin_popcountll(bmask[b]);
@@ -303,21 +319,23 @@ __device__ __forceinline__ uint32_t ps_newid(const unsigned long long* bmask, co
 // without its sweep over every 64-vertex block of the piece and without its plane loop (the first clipping planes are in the list;
 // only a vertex that lies in a plane before its fc is evaluated again, for sh.nzero).  scan: global, ceil(n / 64) + 2 pairs.
 __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const SolidIn in, const uint32_t F, Shared& sh, Topo<InLds>& T, const unsigned long long* bmask,
-                                                                         const uint2* bblk, const uint32_t* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum)
+                                                                         const uint2* bblk, const uint2* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
     STAMP_DECL;
     for (uint32_t t = tid; t < n; t += G)
     {
-        const uint32_t e = klist[t], v = e & 0xFFFFFFu, byte = e >> 24, f = byte & 0x7Fu;
+        const uint2 ke = klist[t];
+        const uint32_t v = ke.x & 0xFFFFFFu, byte = ke.x >> 24, f = byte & 0x7Fu;
         const uint32_t id = ps_newid(bmask, bblk, v, 0u);
-        orig[id] = v;
+        orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
         T.llen[id] = (uint8_t)in.llen[v];
         T.fc[id] = (uint8_t)(f == PS_NEVER ? SURTR_NEVER : f);
         if (f != PS_NEVER) atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u));
         if (byte & 0x80u)
         {
-            const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
+            const float4 pr = in.posr_s[ke.y];
+            const float px = pr.x, py = pr.y, pz = pr.z;
             for (uint32_t k = 0; k < F; ++k)
             {
                 const int c = side_of(plane_dist(sh.planes[k], px, py, pz));
@@ -341,8 +359,9 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const S
     __syncthreads();
     for (uint32_t id = tid; id < n; id += G)
     {
-        const uint32_t v = orig[id];
-        T.pos[3 * id] = in.pos[3 * v]; T.pos[3 * id + 1] = in.pos[3 * v + 1]; T.pos[3 * id + 2] = in.pos[3 * v + 2];
+        const uint32_t v = orig[id] & 0xFFFFu;
+        const float4 pr = in.posr_s[orig[id] >> 16];
+        T.pos[3 * id] = pr.x; T.pos[3 * id + 1] = pr.y; T.pos[3 * id + 2] = pr.z;
         const uint32_t deg = T.llen[id];
         const int32_t* r = in.nbr + in.loff[v];
         uint16_t* d = T.ring + T.loff[id];
@@ -373,13 +392,12 @@ __host__ __device__ static inline RecLayout rec_layout(uint32_t F, uint32_t n)
     return L;
 }
 
-// Emits the band as a record image from the kept list.  bmask / bblk as prepass_select_sorted left them; orig, fcb: global scratch
-// (n words / n bytes); sidmap: global, 16 bits per vertex of the piece, all 0xFFFF on entry and on return -- the sorted id of
-// every band vertex while the rings are written; cnt: >= 5 * (WC_MAXF + 2) words of LDS.  The caller has checked that no band
+// Emits the band as a record image from the kept list.  bmask / bblk as prepass_select_sorted left them; orig, fcb, sid16: global
+// scratch by band index (vertex | sorted index << 16, first clipping plane, sorted id); cnt: >= 5 * (WC_MAXF + 2) words of LDS.  The caller has checked that no band
 // vertex has more than seven ring entries (sh.deg7), F <= WC_MAXF and n < WC_MAXN.
 // ncut_out: planes that are the first clipping plane of some band vertex (the cost estimate of the clip).
 __device__ __attribute__((always_inline)) inline void prepass_emit_records(const SolidIn in, const uint32_t F, Shared& sh, const unsigned long long* bmask, const uint2* bblk,
-                                                                           const uint32_t* klist, uint32_t* orig, uint8_t* fcb, uint16_t* sidmap, uint32_t* cnt,
+                                                                           const uint2* klist, uint32_t* orig, uint8_t* fcb, uint16_t* sid16, uint32_t* cnt,
                                                                            char* img, const uint32_t n, uint32_t& ncut_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
@@ -388,10 +406,11 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
     // ---- band order = ascending vertex index: orig[id], first clipping plane of id ----
     for (uint32_t t = tid; t < n; t += G)
     {
-        const uint32_t e = klist[t], v = e & 0xFFFFFFu;
+        const uint2 ke = klist[t];
+        const uint32_t v = ke.x & 0xFFFFFFu;
         const uint32_t id = ps_newid(bmask, bblk, v, 0u);
-        orig[id] = v;
-        fcb[id] = (uint8_t)((e >> 24) & 0x7Fu);
+        orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
+        fcb[id] = (uint8_t)((ke.x >> 24) & 0x7Fu);
     }
     // sort waves: at most four take part in the ranking (contiguous ranges of 64-vertex blocks of the band)
     const uint32_t nsw = nw < 4u ? nw : 4u;
@@ -411,7 +430,6 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
             const bool valid = id < n;
             const uint32_t f = valid ? (uint32_t)fcb[id] : 0u;
             const uint32_t bk = (f == PS_NEVER || f > F) ? F : f;
-            const uint32_t v = (valid && pass == 1) ? orig[id] : 0u;
             unsigned long long todo = __ballot(valid);
             uint32_t s = 0;
             while (todo)
@@ -425,7 +443,7 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
                 if (valid && bk == k0) s = base + wc_popc64(same & lt);
                 todo &= ~same;
             }
-            if (valid && pass == 1) sidmap[v] = (uint16_t)s;
+            if (valid && pass == 1) sid16[id] = (uint16_t)s;
         }
         if (pass == 1) break;
         __syncthreads();
@@ -457,26 +475,26 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
     float4* gpos = (float4*)(img + lay.gpos);
     for (uint32_t id = tid; id < n; id += G)
     {
-        const uint32_t v = orig[id];
+        const uint32_t vi = orig[id], v = vi & 0xFFFFu;
         const uint32_t f = fcb[id];
         const uint32_t len = in.llen[v];
         const int32_t* r = in.nbr + in.loff[v];
-        const uint32_t s = sidmap[v];
+        const uint32_t s = sid16[id];
+        const float4 pr = in.posr_s[vi >> 16];
         int32_t u[7]; uint32_t e[7];
 #pragma unroll
         for (uint32_t q = 0; q < 7u; ++q) u[q] = r[q < len ? q : 0u];
 #pragma unroll
-        for (uint32_t q = 0; q < 7u; ++q) e[q] = sidmap[u[q]];
+        for (uint32_t q = 0; q < 7u; ++q) e[q] = ps_newid(bmask, bblk, (uint32_t)u[q], 0xFFFFFFFFu);
 #pragma unroll
-        for (uint32_t q = 0; q < 7u; ++q) e[q] = q >= len ? WC_NONE : (e[q] == 0xFFFFu ? WC_SENT : e[q]);
+        for (uint32_t q = 0; q < 7u; ++q) e[q] = q >= len ? WC_NONE : (e[q] == 0xFFFFFFFFu ? WC_SENT : (uint32_t)sid16[e[q]]);
         WcW4 wr;
         wr.a = e[0] | (e[1] << 16); wr.b = e[2] | (e[3] << 16); wr.c = e[4] | (e[5] << 16);
         wr.d = e[6] | (((f == PS_NEVER ? SURTR_NEVER : f) | (len << 8)) << 16);
         grec[s] = wr;
-        gpos[s] = make_float4(in.pos[3 * v], in.pos[3 * v + 1], in.pos[3 * v + 2], __uint_as_float(id));
+        gpos[s] = make_float4(pr.x, pr.y, pr.z, __uint_as_float(id));
     }
-    prepass_finish_hist(F, sh);           // (barriers: every look-up of the map is done)
-    for (uint32_t id = tid; id < n; id += G) sidmap[orig[id]] = (uint16_t)0xFFFFu;
+    prepass_finish_hist(F, sh);
     uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* bs = (uint32_t*)(img + lay.bst);
     for (uint32_t k = tid; k < F; k += G) { hs[k] = sh.hist[k]; zs[k] = sh.zhist[k]; }
     for (uint32_t k = tid; k <= F + 1u; k += G) bs[k] = bst[k];
@@ -486,14 +504,11 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
     STAMP(74);
 }
 
-// The record clipper's state for a pair whose band k_prep_pairs left as a record image: what wc_load sets up, without the sort.
-// The records and positions are COPIED into the workgroup's scratch slot (g, as wc_glob carved it): the plane loop gathers from
-// them and patches them through chains of dependent accesses, and in the slot -- the same bytes pair after pair -- those stay in
-// this XCD's L2, while the image was written by another kernel a while ago and every first touch of it is a trip to HBM
-// (measured with the records used in place: k_clip_pairs_wave 1.75 ms against 1.44 ms).
+// The record clipper's state for a pair whose band k_prep_pairs left as a record image: what wc_load sets up, without the sort and
+// without a copy -- the records and positions are used, and patched, where they are (a copy into the workgroup's scratch slot
+// was measured: the same 1.39 ms for the kernel, 60 KB more written per pair).
 template <class LT>
 __device__ __attribute__((always_inline)) inline int wc_attach(LT& W, const uint32_t* hist, const uint32_t* zhist, const uint32_t* bst, const uint32_t F, const uint32_t n,
-                                                               const WcW4* __restrict__ srec, const float4* __restrict__ spos, const WcGlob g,
                                                                unsigned long long& zmask, WcCtr& ctr, uint32_t* __restrict__ why)
 {
     const uint32_t tid = threadIdx.x;
@@ -501,7 +516,6 @@ __device__ __attribute__((always_inline)) inline int wc_attach(LT& W, const uint
     zmask = 0ull;
     if (F > WC_MAXF || n == 0u || n >= WC_MAXN) WC_RET(1);
     WSTAMP_DECL;
-    for (uint32_t i = tid; i < n; i += group_size()) { g.grec[i] = srec[i]; g.gpos[i] = spos[i]; }
     for (uint32_t k = tid; k < F; k += group_size()) { W.hist[k] = hist[k]; W.zhist[k] = zhist[k]; }
     for (uint32_t k = tid; k <= F + 1u; k += group_size()) W.bst[k] = bst[k];
     if (tid == 0u) { W.zm[0] = 0u; W.zm[1] = 0u; for (int q = 0; q < 6; ++q) (&W.fl[0][0])[q] = 0u; }

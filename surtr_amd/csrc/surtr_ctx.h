@@ -55,9 +55,9 @@ static size_t prep_bytes_per_wg(uint32_t VMAX)
 {
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8) +
-           2 * r((size_t)VMAX + 64) +     // + first clipping planes by sorted index / by band index (prep_sorted.h)
-           2 * r((size_t)VMAX * 4) +      // + kept list, face-walk list
-           r((size_t)VMAX * 2 + 64);      // + vertex -> sorted id of the record emit
+           2 * r((size_t)VMAX + 64) +     // + first clipping planes of the undecided groups' vertices / by band index (prep_sorted.h)
+           r((size_t)VMAX * 8) + r((size_t)VMAX * 4) +      // + kept list (pairs), face-walk list
+           r((size_t)VMAX * 2 + 64);      // + sorted id by band index (record emit)
 }
 
 struct FragRec
@@ -82,6 +82,8 @@ struct Arena
                          // pre-pass class [64..79]=pairs per cost class of k_clip_pairs_half (64 = its retry list)
 };
 
+struct alignas(16) SRow { uint32_t w[4]; };
+
 struct Pieces
 {
     const float* mpos; const uint32_t* mloff; const uint32_t* mllen; const int32_t* mnbr; const uint32_t* mvo; const uint8_t* mtri; const float* mrad;
@@ -93,12 +95,13 @@ struct Pieces
     // solid need not close, and where the reference's bounded walk stops then depends on its vertex count of the moment: these
     // solids take the literal clipper (literal_clip.h) from the start.
     const uint8_t* mdup; const uint8_t* cdup;
-    // the Mesh rings once more in SORTED space (round 4, pieces_dev.hip): sorted slot i (global over the set) has the header
-    // mhdr_s[i] = (first entry in mnbr_s, ring length | bit 31: some incident face is no triangle) and the ring
-    // mnbr_s[x .. x + length) whose entries are piece-local SORTED indices.  The pre-pass of k_prep_pairs looks the first
-    // clipping plane of a neighbour up by its sorted index.
+    // the Mesh rings once more in SORTED space (round 4, pieces_dev.hip): sorted slot i (global over the set) has the 16-byte row
+    // mrow_s[i] = eight 16-bit words: header (ring length 0..7 | 0x80: some incident face is no triangle | 0x40: more than seven
+    // neighbours, not listed), then the neighbours as piece-local SORTED indices (pieces of up to 65 535 vertices; 0xFFFF: none).
+    // One aligned load gives the pre-pass of k_prep_pairs a vertex's whole ring; it looks the first clipping plane of a
+    // neighbour up by that index.  miperm: sorted index of every vertex.
     // mbsph2 / mbsph3: one sphere per 8 / 64 of the SURTR_SB-vertex spheres (mbo2 / mbo3: first such sphere of every piece)
-    const uint2* mhdr_s; const int32_t* mnbr_s;
+    const SRow* mrow_s; const uint32_t* miperm;
     const float4* mbsph2; const uint32_t* mbo2; const float4* mbsph3; const uint32_t* mbo3;
 };
 
@@ -171,14 +174,14 @@ struct PieceSet
     float* box = nullptr; unsigned long long* key = nullptr; unsigned long long* key2 = nullptr; uint32_t* val = nullptr;    // Morton sort
     uint8_t* dup = nullptr; size_t c_dup = 0;       // per piece: a ring lists a neighbour twice
     // rings in sorted space + two coarser sphere levels (see Pieces)
-    uint32_t* iperm = nullptr; uint32_t* loff_s = nullptr; int32_t* nbr_s = nullptr; uint2* hdr_s = nullptr;
+    uint32_t* iperm = nullptr; SRow* row_s = nullptr;
     float4* bsph2 = nullptr; uint32_t* bo2 = nullptr; float4* bsph3 = nullptr; uint32_t* bo3 = nullptr;
-    size_t c_iperm = 0, c_loff_s = 0, c_nbr_s = 0, c_hdr_s = 0, c_bsph2 = 0, c_bo2 = 0, c_bsph3 = 0, c_bo3 = 0;
+    size_t c_iperm = 0, c_row_s = 0, c_bsph2 = 0, c_bo2 = 0, c_bsph3 = 0, c_bo3 = 0;
     size_t c_pos = 0, c_loff = 0, c_llen = 0, c_nbr = 0, c_vo = 0, c_tri = 0, c_rad = 0, c_perm = 0, c_posr_s = 0, c_bsph = 0,
            c_bo = 0, c_box = 0, c_key = 0, c_key2 = 0, c_val = 0;
     void release()
     {
-        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val, dup, iperm, loff_s, nbr_s, hdr_s, bsph2, bo2, bsph3, bo3};
+        void* all[] = {pos, loff, llen, nbr, vo, tri, rad, perm, posr_s, bsph, bo, box, key, key2, val, dup, iperm, row_s, bsph2, bo2, bsph3, bo3};
         for (void* p : all) if (p) (void)hipFree(p);
         *this = PieceSet();
     }

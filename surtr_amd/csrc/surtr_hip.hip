@@ -775,9 +775,9 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint8_t* vfc = (uint8_t*)take((size_t)pool.VMAX + 64);
     uint8_t* fcb = (uint8_t*)take((size_t)pool.VMAX + 64);
-    uint32_t* klist = (uint32_t*)take((size_t)pool.VMAX * 4);
+    uint2* klist = (uint2*)take((size_t)pool.VMAX * 8);
     uint32_t* walks = (uint32_t*)take((size_t)pool.VMAX * 4);
-    uint16_t* sidmap = (uint16_t*)take((size_t)pool.VMAX * 2 + 64);      // all 0xFFFF between pairs (ensure_prep sets it, prepass_emit_records restores it)
+    uint16_t* sid16 = (uint16_t*)take((size_t)pool.VMAX * 2 + 64);
 #ifdef SURTR_STAMP
     const unsigned long long wg_t0 = __builtin_readcyclecounter();
     unsigned long long wg_work = 0;
@@ -836,10 +836,10 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
 #endif
         // a piece with a sorted copy whose groups fit the LDS table: selection by sphere hierarchy and fc look-ups (prep_sorted.h)
         constexpr uint32_t kUbWords = (SURTR_PREP_NB - SURTR_PS_NB) * 2u;      // the tail of lblk as 32-bit words: one bit per group
-        const bool sorted_sel = !(rec_on & 2u) && nbV <= SURTR_PS_NB && (V + SURTR_SB - 1u) / SURTR_SB <= 32u * kUbWords && V < (1u << 24) && P.mhdr_s != nullptr;
+        const bool sorted_sel = !(rec_on & 2u) && nbV <= SURTR_PS_NB && (V + SURTR_SB - 1u) / SURTR_SB <= 32u * kUbWords && V < 0xFFFFu && P.mrow_s != nullptr;
         if (sorted_sel)
         {
-            const SortedRings sr{P.mhdr_s + m0, P.mnbr_s, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
+            const SortedRings sr{P.mrow_s + m0, P.miperm + m0, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
             prepass_select_sorted(min, sr, F, sh, lmask, lblk, (uint32_t*)(lblk + SURTR_PS_NB), kUbWords, vfc, needy, und, klist, walks, n, hsum);
         }
         else prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
@@ -869,7 +869,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             if ((uint64_t)off16 + need16 > IA.cap16) fmt = IMG_NONE;      // arena full: the clip kernel does this pair alone
             else
             {
-                prepass_emit_records(min, F, sh, bmask, bblk, klist, orig, fcb, sidmap, sh.pw, IA.base + (size_t)off16 * 16u, n, ncut_rec);
+                prepass_emit_records(min, F, sh, bmask, bblk, klist, orig, fcb, sid16, sh.pw, IA.base + (size_t)off16 * 16u, n, ncut_rec);
                 fmt = IMG_REC;
             }
         }
@@ -1260,12 +1260,12 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
             WcGlob g;
             if (rec.img_fmt == IMG_REC)
             {
-                // the band is there as the record clipper streams it (k_prep_pairs, prep_sorted.h): copied into this workgroup's
-                // scratch slot, no sort
+                // the band is there as the record clipper streams it (k_prep_pairs, prep_sorted.h): used, and patched, in place; this
+                // workgroup's scratch slot only holds the positions of the cut points
                 const RecLayout rl = rec_layout(F, rec.img_n);
-                g = wc_glob(slot, pool.per_wg, rec.img_n, 2u * WL::kNR, fits);
-                if (fits) err = wc_attach(W, (const uint32_t*)(img + rl.hist), (const uint32_t*)(img + rl.zhist), (const uint32_t*)(img + rl.bst), F, rec.img_n,
-                                          (const WcW4*)(img + rl.grec), (const float4*)(img + rl.gpos), g, zmask, ctr, A.cursors + 96);
+                g.grec = (WcW4*)(img + rl.grec); g.gpos = (float4*)(img + rl.gpos); g.cpos = (float4*)slot;
+                fits = 16u * (size_t)(2u * WL::kNR) <= pool.per_wg;
+                if (fits) err = wc_attach(W, (const uint32_t*)(img + rl.hist), (const uint32_t*)(img + rl.zhist), (const uint32_t*)(img + rl.bst), F, rec.img_n, zmask, ctr, A.cursors + 96);
             }
             else
             {
@@ -1292,8 +1292,8 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
                 }
             }
 #endif
-            // the general clipper has no use for a record image: for a pair the record clipper gives up on it starts from the piece
-            // (its own pre-pass), as for a pair that never had an image
+            // a record image the clipper gave up on has been patched by the planes it did (and the general clipper has no use for
+            // records anyway): it starts from the piece (its own pre-pass), as for a pair that never had an image
             if (err == WC_BAIL && rec.img_fmt == IMG_REC) { rec.img_fmt = IMG_NONE; if (tid == 0) atomicAdd(&A.cursors[93], 1u); }
         }
         if (tid == 0) atomicAdd(&A.cursors[err == WC_BAIL ? 89 : 88], 1u);       // (diagnostic: pairs the record clipper took / handed on)
@@ -3056,8 +3056,6 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
         free_dev(ctx->prep.base); ctx->prep.base = nullptr;
         ctx->prep.VMAX = VMAX; ctx->prep.per_wg = prep_bytes_per_wg(VMAX); ctx->n_wg_prep = n_wg;
         HIPCHK(hipMalloc((void**)&ctx->prep.base, ctx->prep.per_wg * n_wg));
-        // the vertex -> sorted id map of the record emit is all ones between pairs (the rest of the scratch is written before it is read)
-        HIPCHK(hipMemsetAsync(ctx->prep.base, 0xFF, ctx->prep.per_wg * n_wg, ctx->stream));
     }
     if (ctx->cap_order < n_pairs)
     {
@@ -3196,7 +3194,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     const PieceSet& M = ctx->mset; const PieceSet& C = ctx->cset;
     Pieces P{M.pos, M.loff, M.llen, M.nbr, M.vo, M.tri, M.rad, M.perm, M.posr_s, M.bsph, M.bo,
              C.pos, C.loff, C.llen, C.nbr, C.vo, C.tri, C.rad, C.perm, C.posr_s, C.bsph, C.bo, ctx->n_pieces, M.dup, C.dup,
-             M.hdr_s, M.nbr_s, M.bsph2, M.bo2, M.bsph3, M.bo3};
+             M.row_s, M.iperm, M.bsph2, M.bo2, M.bsph3, M.bo3};
     for (int i = 0; i < 16; ++i) ctx->ev_valid[i] = false;
     const uint32_t* d_pair_order = nullptr;
     if (d_pair_list && ctx->pair_order_is_list && ctx->pair_order_count == n_pairs) d_pair_order = ctx->d_pair_order;      // surtr_fracture_pairs_async made it
