@@ -445,7 +445,8 @@ __device__ __forceinline__ void prepass_keep_deg(uint2* bblk, Shared& sh, uint32
 
 // A2 of the pre-pass: the exact test, densely over the work list `needy` (v | fc << 24): a vertex is dropped iff every vertex
 // of every incident face has the same first clipping plane.  klist / kcount (optional, the sorted pre-pass of k_prep_pairs): the
-// kept vertices are appended as (vertex | (first clipping plane | 0x80 when the vertex lies in an earlier plane) << 24, sorted index);
+// kept vertices are appended as (vertex | (first clipping plane | 0x80 when the vertex lies in an earlier plane) << 24, sorted index
+// | ring length << 16);
 // sh.misc[5] = some kept vertex does.
 template <int NB>
 __device__ inline void prepass_exact(const SolidIn in, const uint32_t F, Shared& sh, unsigned long long* bmask, uint2* bblk,
@@ -506,14 +507,14 @@ __device__ inline void prepass_exact(const SolidIn in, const uint32_t F, Shared&
             drop = !keep;
             if (keep)
             {
-                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-                keep_deg(v, deg);
+                // (the sorted pre-pass builds its masks from the kept list afterwards: bmask == nullptr)
+                if (bmask != nullptr) { atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u))); keep_deg(v, deg); }
                 if (klist != nullptr)
                 {
                     const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
                     uint32_t z = 0;
                     for (uint32_t k = 0; k < f; ++k) if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) z = 0x80u;
-                    klist[atomicAdd(kcount, 1u)] = make_uint2(v | ((f | z) << 24), iperm[v]);
+                    klist[atomicAdd(kcount, 1u)] = make_uint2(v | ((f | z) << 24), iperm[v] | ((deg < 255u ? deg : 255u) << 16));
                     if (z) sh.misc[5] = 1u;
                 }
             }

@@ -81,23 +81,28 @@ __device__ __forceinline__ void ps_append2(uint2* list, uint32_t* counter, bool 
     if (on) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull))] = value;
 }
 
-// Selection.  bmask / bblk: LDS, one word / pair per 64 vertices; ub: LDS, one bit per group ("undecided"), ubWords words
-// (ubWords <= the entries of bblk: bblk[q].x holds the set bits before word q until the kept vertices are counted);
-// vfc: global bytes, DENSE: the vertices of the undecided groups in ascending group order (a table by vertex would be written and
-// read a few bytes per cache line: 0.7 GB per configs[3] event, measured); needy, und, klist, walks: global work lists
-// (V entries each at most; und: one per group).
-// Requires in.nv < 65535, ceil(in.nv / SURTR_SB) <= 32 * ubWords, room for the 16-bit lists of A0 in bblk (the caller's
-// SURTR_PS_NB rule), the sorted copy.
-// Leaves: the kept vertices as bits of bmask AND as klist[0 .. n) = (vertex | (fc | 0x80: in a plane before fc) << 24, sorted
-// index), in no order; bblk scanned (x: kept vertices before the block, y: their ring entries); sh.hist / zhist raw
-// (prepass_finish_hist); sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7.
+// Selection.  lbuf: the kernel's LDS table area, 16 * NB bytes (NB = 64-vertex blocks it is sized for).  While the band is
+// selected it holds: the first clipping planes of the undecided groups' vertices (bytes, in ascending group order; what does
+// not fit goes to vfc_g), then `ubw` words "set bits before this word" and `ubw` words of one bit per group ("undecided").
+// On return it holds what the emits read: bmask (one 64-bit word per 64 vertices, first half) and bblk (one pair per 64
+// vertices, second half; x: kept vertices before the block, y: their ring entries), built from the kept list.
+// vfc_g, needy, und, klist, walks: global scratch (V entries each at most; und: one per group).
+// Requires in.nv < 65535, ceil(in.nv / SURTR_SB) <= 32 * ubw, in.nv <= 64 * NB, the sorted copy.
+// Leaves: klist[0 .. n) = (vertex | (fc | 0x80: in a plane before fc) << 24, sorted index | ring length << 16), in no order;
+// sh.hist / zhist raw (prepass_finish_hist); sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7, sh.flagBad.
+template <uint32_t NB, uint32_t UBW>
 __device__ __attribute__((always_inline)) inline void prepass_select_sorted(const SolidIn in, const SortedRings sr, const uint32_t F, Shared& sh,
-                                                                            unsigned long long* bmask, uint2* bblk, uint32_t* ub, const uint32_t ubWords,
-                                                                            uint8_t* vfc, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
+                                                                            unsigned char* lbuf, uint8_t* vfc_g, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
                                                                             uint32_t& n_out, uint32_t& hsum_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
     const uint32_t V = in.nv;
+    constexpr uint32_t kCap = 16u * NB - 8u * UBW;          // bytes of the byte table that fit
+    uint8_t* vfc = lbuf;
+    uint32_t* pre = (uint32_t*)(lbuf + kCap);
+    uint32_t* ub = pre + UBW;
+    unsigned long long* bmask = (unsigned long long*)lbuf;
+    uint2* bblk = (uint2*)(lbuf + 8u * NB);
     STAMP_DECL;
     for (uint32_t k = tid; k <= SURTR_MAXF; k += G)
     {
@@ -113,14 +118,13 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     // misc: 1, 2 undecided spheres of levels 3, 2; 3 needy; 4 undecided groups; 5 in-plane kept vertex; 6 kept; 0 face walks
     if (tid == 0) { sh.flagErr = 0; sh.flagBad = 0; sh.deg7 = 0; for (int q = 0; q < 7; ++q) sh.misc[q] = 0; }
     const uint32_t nbV = (V + SURTR_LANES - 1u) >> SURTR_LSH;
-    for (uint32_t b = tid; b < nbV; b += G) bmask[b] = 0ull;
-    for (uint32_t q = tid; q < ubWords; q += G) ub[q] = 0u;
+    for (uint32_t q = tid; q < UBW; q += G) ub[q] = 0u;
     __syncthreads();
-    // ---- A0: spheres, coarse to fine.  Work lists of undecided spheres (16-bit ids) live in the bytes of bblk until A0 is done.
-    //      A decided sphere only counts its vertices (all dropped with one fc); an undecided group sets its bit. ----
+    // ---- A0: spheres, coarse to fine.  Work lists of undecided spheres (16-bit ids) live at the start of the byte table until
+    //      A0 is done.  A decided sphere only counts its vertices (all dropped with one fc); an undecided group sets its bit. ----
     const uint32_t nsb = (V + SURTR_SB - 1u) / SURTR_SB;
     const uint32_t nb2 = (nsb + SURTR_SPH_FAN - 1u) / SURTR_SPH_FAN, nb3 = (nb2 + SURTR_SPH_FAN - 1u) / SURTR_SPH_FAN;
-    uint16_t* list2 = (uint16_t*)bblk;                 // undecided level-2 spheres (nb2 of them at most)
+    uint16_t* list2 = (uint16_t*)lbuf;                 // undecided level-2 spheres (nb2 of them at most)
     uint16_t* list3 = list2 + nb2 + 8u;                // undecided level-3 spheres
     auto verts_in = [&](uint32_t g0, uint32_t g1) -> uint32_t {      // vertices of groups [g0, g1)
         const uint32_t a = g0 * SURTR_SB, b = g1 * SURTR_SB;
@@ -154,26 +158,23 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         else atomicOr(&ub[sb >> 5], 1u << (sb & 31u));
     }
     __syncthreads();
-    // the undecided groups in ascending (Morton) order, from the bits: the 64 vertices of a wave-load of P1 are then neighbours
-    // in space -- their plane loops end together, their loads share cache lines -- and so are the entries of the lists P1 fills
-    for (uint32_t b = tid; b < nbV; b += G) bblk[b] = make_uint2(0u, 0u);      // (the lists are done with)
-    __syncthreads();
+    // the undecided groups in ascending (Morton) order, from the bits: und[rank] = group, pre[q] = set bits before word q.  The
+    // rank of a group is also where its vertices' bytes sit in the table.
     {
-        // und[rank] = group, rank = set bits before it (a scan over the words)
         uint32_t carry = 0;
-        for (uint32_t q0 = 0; q0 < ubWords; q0 += G)
+        for (uint32_t q0 = 0; q0 < UBW; q0 += G)
         {
             const uint32_t q = q0 + tid;
-            const uint32_t c = q < ubWords ? (uint32_t)__builtin_popcount(ub[q]) : 0u;
+            const uint32_t c = q < UBW ? (uint32_t)__builtin_popcount(ub[q]) : 0u;
             const uint32_t inc = wave_incl_scan2(make_uint2(c, 0u)).x;
             if (l == SURTR_LANES - 1u) sh.wsum[w] = inc;
             __syncthreads();
             uint32_t woff = 0, tot = 0;
             for (uint32_t x = 0; x < nw; ++x) { const uint32_t a = sh.wsum[x]; if (x < w) woff += a; tot += a; }
-            if (q < ubWords)
+            if (q < UBW)
             {
                 uint32_t at = carry + woff + inc - c;
-                bblk[q].x = at;
+                pre[q] = at;
                 for (uint32_t m = ub[q]; m; m &= m - 1u) und[at++] = 32u * q + (uint32_t)__builtin_ctz(m);
             }
             carry += tot;
@@ -188,9 +189,9 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
 #endif
     STAMP(44);
     // ---- P1: first clipping plane of every vertex of the undecided groups (ComparePlanePoint, Src/Poly.cpp:716-723: clipped iff
-    //      s >= 1e-10f, in the plane iff |s| < 1e-10f -- side_of() spelled without its branches), stored as a byte by sorted
-    //      index; and the ball test of prepass_select: a clipped vertex whose ball (every vertex of its incident faces) stays
-    //      strictly on its side of every plane up to its first clipping plane is dropped here, the others go to P2 ----
+    //      s >= 1e-10f, in the plane iff |s| < 1e-10f -- side_of() spelled without its branches), stored as a byte at (rank of
+    //      the group) * SB + place; and the ball test of prepass_select: a clipped vertex whose ball (every vertex of its incident
+    //      faces) stays strictly on its side of every plane up to its first clipping plane is dropped here, the others go to P2 ----
     constexpr uint32_t GPW = SURTR_LANES / SURTR_SB;      // groups per wave-load
     const uint32_t nWork = (nUnd + GPW - 1u) / GPW;
     for (uint32_t wb = w; wb < nWork; wb += nw)
@@ -215,7 +216,8 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
             f = (live & cut) ? k : f;
             done = done | cut;
         }
-        if (valid) vfc[sub * SURTR_SB + (l % SURTR_SB)] = (uint8_t)(f | z);
+        const uint32_t at = sub * SURTR_SB + (l % SURTR_SB);
+        if (valid) { if (at < kCap) vfc[at] = (uint8_t)(f | z); else vfc_g[at] = (uint8_t)(f | z); }
         const bool never = valid && f == PS_NEVER;
         const bool drop = valid && !never && clear;          // (|s| > margin at every plane up to fc: in no plane either)
         const bool need = valid && !never && !clear;
@@ -225,20 +227,16 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         {
             // never clipped: kept whatever its neighbours are
             const uint32_t v = never ? in.perm[i] : 0u;
-            if (never)
-            {
-                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-                prepass_keep_deg(bblk, sh, v, in.llen[v]);
-                if (z) sh.misc[5] = 1u;
-            }
-            ps_append2(klist, &sh.misc[6], never, make_uint2(v | ((f | z) << 24), i));
+            const uint32_t deg = never ? in.llen[v] : 0u;
+            if (never && z) sh.misc[5] = 1u;
+            ps_append2(klist, &sh.misc[6], never, make_uint2(v | ((f | z) << 24), i | ((deg < 255u ? deg : 255u) << 16)));
         }
     }
     __syncthreads();
     STAMP(0);
     // ---- P2, densely over the vertices the ball test left: dropped iff all neighbours share the first clipping plane.  A
     //      neighbour in a decided group does (see the head of this file); one in an undecided group has its byte.  Vertices
-    //      with a face that is no triangle go on to the exact test with face walks (prepass_exact). ----
+    //      with a face that is no triangle, or more than seven neighbours, go on to the exact test with face walks (prepass_exact). ----
     const uint32_t nNeedy = sh.misc[3];
 #ifdef SURTR_STAMP
     if (tid == 0 && V > 10000u) atomicAdd(&g_stamp[47], (unsigned long long)nNeedy);
@@ -258,14 +256,15 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         for (int q = 0; q < 7; ++q)
         {
             const uint32_t x = row.w[(q + 1) >> 1];
-            uq[q] = ((q + 1) & 1) ? (x >> 16) : (x & 0xFFFFu);
-            const uint32_t u = (uint32_t)q < deg ? uq[q] : 0u;
+            const uint32_t u = (uint32_t)q < deg ? (((q + 1) & 1) ? (x >> 16) : (x & 0xFFFFu)) : 0u;
             const uint32_t g = u / SURTR_SB, word = ub[g >> 5], bit = g & 31u;
             on[q] = ((uint32_t)q < deg ? 1u : 0u) & ((word >> bit) & 1u);
-            uq[q] = (bblk[g >> 5].x + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))) * SURTR_SB + u % SURTR_SB;
+            uq[q] = (pre[g >> 5] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))) * SURTR_SB + u % SURTR_SB;
         }
 #pragma unroll
-        for (int q = 0; q < 7; ++q) fq[q] = on[q] ? ((uint32_t)vfc[uq[q]] & 0x7Fu) : f;
+        for (int q = 0; q < 7; ++q) fq[q] = (on[q] && uq[q] < kCap) ? ((uint32_t)vfc[uq[q]] & 0x7Fu) : f;
+#pragma unroll
+        for (int q = 0; q < 7; ++q) if (on[q] && uq[q] >= kCap) fq[q] = (uint32_t)vfc_g[uq[q]] & 0x7Fu;      // (a band beyond the table: rare)
         bool differ = false;
 #pragma unroll
         for (int q = 0; q < 7; ++q) differ = differ | (fq[q] != f);
@@ -275,13 +274,8 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         if (__ballot(keep | walk))
         {
             const uint32_t v = (keep | walk) ? in.perm[i] : 0u;
-            if (keep)
-            {
-                atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
-                prepass_keep_deg(bblk, sh, v, deg);
-                if (byte & 0x80u) sh.misc[5] = 1u;
-            }
-            ps_append2(klist, &sh.misc[6], keep, make_uint2(v | (byte << 24), i));
+            if (keep && (byte & 0x80u)) sh.misc[5] = 1u;
+            ps_append2(klist, &sh.misc[6], keep, make_uint2(v | (byte << 24), i | (deg << 16)));
             ps_append(walks, &sh.misc[0], walk, v | (f << 24));
         }
         wave_hist_add(sh.hist, f, drop);
@@ -294,16 +288,30 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         }
     }
     __syncthreads();
-    if (sh.misc[0] != 0u) prepass_exact<4>(in, F, sh, bmask, bblk, walks, sh.misc[0], klist, &sh.misc[6], sr.iperm);
+    if (sh.misc[0] != 0u) prepass_exact<4>(in, F, sh, (unsigned long long*)nullptr, (uint2*)nullptr, walks, sh.misc[0], klist, &sh.misc[6], sr.iperm);
     __syncthreads();
     STAMP(1);
+    // ---- the masks the emits number the band with, from the kept list (the table area is free now) ----
+    const uint32_t n = sh.misc[6];
+    for (uint32_t b = tid; b < nbV; b += G) { bmask[b] = 0ull; bblk[b] = make_uint2(0u, 0u); }
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += G)
+    {
+        const uint2 ke = klist[t];
+        const uint32_t v = ke.x & 0xFFFFFFu, deg = ke.y >> 16;
+        atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
+        uint32_t d = deg;
+        if (deg >= 255u) d = in.llen[v];
+        prepass_keep_deg(bblk, sh, v, d);
+    }
+    __syncthreads();
     for (uint32_t b = tid; b < nbV; b += G) bblk[b].x = (uint32_t)__builtin_popcountll(bmask[b]);
     __syncthreads();
-    uint32_t n = 0, hsum = 0;
-    scan_block_array(nbV, bblk, sh, n, hsum);
+    uint32_t n2 = 0, hsum = 0;
+    scan_block_array(nbV, bblk, sh, n2, hsum);
     __syncthreads();
     STAMP(3);
-    n_out = n; hsum_out = hsum;
+    n_out = n2; hsum_out = hsum;
 }
 
 // index of vertex u in the band (ascending vertex index), or `absent`
@@ -329,12 +337,12 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const S
         const uint32_t v = ke.x & 0xFFFFFFu, byte = ke.x >> 24, f = byte & 0x7Fu;
         const uint32_t id = ps_newid(bmask, bblk, v, 0u);
         orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
-        T.llen[id] = (uint8_t)in.llen[v];
+        T.llen[id] = (uint8_t)((ke.y >> 16) < 255u ? (ke.y >> 16) : in.llen[v]);
         T.fc[id] = (uint8_t)(f == PS_NEVER ? SURTR_NEVER : f);
         if (f != PS_NEVER) atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u));
         if (byte & 0x80u)
         {
-            const float4 pr = in.posr_s[ke.y];
+            const float4 pr = in.posr_s[ke.y & 0xFFFFu];
             const float px = pr.x, py = pr.y, pz = pr.z;
             for (uint32_t k = 0; k < F; ++k)
             {

@@ -835,12 +835,12 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
 #define SURTR_PREP_NBATCH 4
 #endif
         // a piece with a sorted copy whose groups fit the LDS table: selection by sphere hierarchy and fc look-ups (prep_sorted.h)
-        constexpr uint32_t kUbWords = (SURTR_PREP_NB - SURTR_PS_NB) * 2u;      // the tail of lblk as 32-bit words: one bit per group
-        const bool sorted_sel = !(rec_on & 2u) && nbV <= SURTR_PS_NB && (V + SURTR_SB - 1u) / SURTR_SB <= 32u * kUbWords && V < 0xFFFFu && P.mrow_s != nullptr;
+        constexpr uint32_t kUbWords = (SURTR_PREP_NB - SURTR_PS_NB) * 2u;      // 32-bit words of one bit per group (the tail of the table area)
+        const bool sorted_sel = !(rec_on & 2u) && nbV <= SURTR_PREP_NB && (V + SURTR_SB - 1u) / SURTR_SB <= 32u * kUbWords && V < 0xFFFFu && P.mrow_s != nullptr;
         if (sorted_sel)
         {
             const SortedRings sr{P.mrow_s + m0, P.miperm + m0, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
-            prepass_select_sorted(min, sr, F, sh, lmask, lblk, (uint32_t*)(lblk + SURTR_PS_NB), kUbWords, vfc, needy, und, klist, walks, n, hsum);
+            prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, needy, und, klist, walks, n, hsum);
         }
         else prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
@@ -964,8 +964,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
 {
     __shared__ Shared sh;
-    __shared__ unsigned long long lmask[SURTR_PREP_NB];
-    __shared__ uint2 lblk[SURTR_PREP_NB];
+    __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
+    unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
     prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
@@ -980,8 +980,8 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
 {
     __shared__ Shared sh;
-    __shared__ unsigned long long lmask[SURTR_PREP_NB];
-    __shared__ uint2 lblk[SURTR_PREP_NB];
+    __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
+    unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
     prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
 }
 
