@@ -22,6 +22,6 @@ for _ in range(10):
         if v >= 0: acc.setdefault(k, []).append(v)
 q = eng.queue_stats()
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("SURTR_")) or "default"
-print("%s: event ms min %.3f median %.3f | record clipper took %d handed on %d | record images %d (given up on: %d) | kernels (median ms) %s" % (tag, ts[0], ts[len(ts) // 2],
-      int(q[88]), int(q[89]), int(q[91]), int(q[93]), {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
+print("%s: event ms min %.3f median %.3f | record clipper took %d handed on %d %s | record images %d (given up on: %d) | kernels (median ms) %s" % (tag, ts[0], ts[len(ts) // 2],
+      int(q[88]), int(q[89]), {i: int(q[96 + i]) for i in range(1, 20) if q[96 + i]}, int(q[91]), int(q[93]), {k: round(float(np.median(v)), 3) for k, v in acc.items() if np.median(v) > 0.02}), flush=True)
 eng.close()

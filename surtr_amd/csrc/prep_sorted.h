@@ -403,10 +403,11 @@ __host__ __device__ static inline RecLayout rec_layout(uint32_t F, uint32_t n)
 // Emits the band as a record image from the kept list.  bmask / bblk as prepass_select_sorted left them; orig, fcb, sid16: global
 // scratch by band index (vertex | sorted index << 16, first clipping plane, sorted id); cnt: >= 5 * (WC_MAXF + 2) words of LDS.  The caller has checked that no band
 // vertex has more than seven ring entries (sh.deg7), F <= WC_MAXF and n < WC_MAXN.
-// ncut_out: planes that are the first clipping plane of some band vertex (the cost estimate of the clip).
+// ncut_out: planes that are the first clipping plane of some band vertex (the cost estimate of the clip); maxb_out: the largest
+// number of band vertices one plane clips (what the record clipper's LDS need at its worst plane follows).
 __device__ __attribute__((always_inline)) inline void prepass_emit_records(const SolidIn in, const uint32_t F, Shared& sh, const unsigned long long* bmask, const uint2* bblk,
                                                                            const uint2* klist, uint32_t* orig, uint8_t* fcb, uint16_t* sid16, uint32_t* cnt,
-                                                                           char* img, const uint32_t n, uint32_t& ncut_out)
+                                                                           char* img, const uint32_t n, uint32_t& ncut_out, uint32_t& maxb_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
     const RecLayout lay = rec_layout(F, n);
@@ -506,9 +507,9 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
     uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* bs = (uint32_t*)(img + lay.bst);
     for (uint32_t k = tid; k < F; k += G) { hs[k] = sh.hist[k]; zs[k] = sh.zhist[k]; }
     for (uint32_t k = tid; k <= F + 1u; k += G) bs[k] = bst[k];
-    uint32_t ncut = 0;
-    for (uint32_t k = 0; k < F; ++k) ncut += bst[k + 1u] != bst[k] ? 1u : 0u;
-    ncut_out = ncut;
+    uint32_t ncut = 0, maxb = 0;
+    for (uint32_t k = 0; k < F; ++k) { const uint32_t c = bst[k + 1u] - bst[k]; ncut += c != 0u ? 1u : 0u; maxb = c > maxb ? c : maxb; }
+    ncut_out = ncut; maxb_out = maxb;
     STAMP(74);
 }
 

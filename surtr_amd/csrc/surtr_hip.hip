@@ -759,12 +759,14 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                          uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t small_cap)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
     auto enqueue = [&](uint32_t p, uint32_t cls) { order[(size_t)cls * n_pairs + atomicAdd(&A.cursors[16u + cls], 1u)] = p; };
     auto enqueue_half = [&](uint32_t p, uint32_t cls) { horder[(size_t)cls * n_pairs + atomicAdd(&A.cursors[64u + cls], 1u)] = p; };
+    // the small tier of the record clipper (k_clip_pairs_rec): its table follows the half kernel's
+    auto enqueue_small = [&](uint32_t p, uint32_t cls) { horder[(size_t)(16u + cls) * n_pairs + atomicAdd(&A.cursors[128u + cls], 1u)] = p; };
     const uint32_t tid = threadIdx.x;
     char* sp = pool.base + (size_t)blockIdx.x * pool.per_wg;
     auto take = [&](size_t bytes) { char* r = sp; sp += (bytes + 255) & ~(size_t)255; return r; };
@@ -857,7 +859,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         const bool rec_fmt = (rec_on & 1u) != 0u && sorted_sel && fmt == IMG_NARROW && !to_half && F <= WC_MAXF && n < WC_MAXN && n <= (rec_on >> 8) &&
                              sh.misc[5] == 0u && sh.deg7 == 0u && P.mdup[piece] == 0 &&
                              (fits_with_room(n, hsum, capV, SURTR_LH) || big_quota == 0xFFFFFFFFu);
-        uint32_t ncut_rec = 0;
+        uint32_t ncut_rec = 0, maxb_rec = 0;
         if (rec_fmt)
         {
             const RecLayout rl = rec_layout(F, n);
@@ -869,7 +871,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             if ((uint64_t)off16 + need16 > IA.cap16) fmt = IMG_NONE;      // arena full: the clip kernel does this pair alone
             else
             {
-                prepass_emit_records(min, F, sh, bmask, bblk, klist, orig, fcb, sid16, sh.pw, IA.base + (size_t)off16 * 16u, n, ncut_rec);
+                prepass_emit_records(min, F, sh, bmask, bblk, klist, orig, fcb, sid16, sh.pw, IA.base + (size_t)off16 * 16u, n, ncut_rec, maxb_rec);
                 fmt = IMG_REC;
             }
         }
@@ -944,7 +946,14 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                 else if (cls < 12u && (fmt == IMG_NARROW || fmt == IMG_REC) && n > big_n && n < WC_MAXN) cls = 14u;
             }
             else if (cls >= 14u && fmt != IMG_EMPTY && atomicAdd(&A.cursors[84], 1u) >= big_quota) cls = 13u;
-            if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);      // (a record image is never to_half)
+            // The small tier takes the record images whose worst plane will fit its LDS: the need follows the band size and the largest
+            // bucket (measured on configs[3], scripts/wave_need.py: need ~ 5.15 n + 41.85 maxbucket + 393 bytes, residual sigma 2.3 KB),
+            // of which 16 bytes per vertex of the bucket are the stage, which a plane leaves in global memory when it must
+            // (wave_clip.h); what does not fit after all comes back through class 12 of the large tier
+            const uint32_t s_cap = small_cap;
+            const bool to_small = s_cap != 0u && fmt == IMG_REC && cls < 12u && (515u * n + 2585u * maxb_rec) / 100u + 393u + 4096u <= s_cap;
+            if (to_small) enqueue_small(p, cls);
+            else if (fmt == IMG_NARROW && to_half) enqueue_half(p, cls < 6u ? cls : 6u);      // (a record image is never to_half)
             else if (fmt != IMG_EMPTY) enqueue(p, cls);
         }
 #ifdef SURTR_STAMP
@@ -961,12 +970,12 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
     unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
-    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -977,12 +986,12 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
     unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
-    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -1205,7 +1214,10 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_big(Pieces P, const flo
 // the same LDS bytes: k_prep_pairs puts the pairs it knows to be irregular into the heaviest class, so they come first.
 struct GenLds { Shared sh; LdsTopo L; };
 struct GenLdsBig { Shared sh; LdsTopoBig L; };
-template <class WL, class GL>
+// FALLBACK = false: the small tier (k_clip_pairs_rec) -- record images only, no general clipper in the kernel (its LDS and registers
+// are the record clipper's alone: three workgroups per CU); a pair it gives up on goes to class 12 of the large tier's table,
+// whose kernel runs behind this one.
+template <class WL, class GL, bool FALLBACK = true>
 __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_body(unsigned char* lds_raw, uint32_t wg, const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
@@ -1219,7 +1231,9 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
     // this workgroup's scratch slot: used raw by the record clipper (sorted records + positions of a band's originals, positions
     // of the cut points), carved as a Scratch by the general clipper
     char* slot = pool.base + (size_t)wg * pool.per_wg;
-    Scratch S = carve(pool, wg);
+    Scratch S{};
+    if (FALLBACK) S = carve(pool, wg);
+    const uint32_t cbase = FALLBACK ? 16u : 128u;       // class counts of the table this kernel pulls from
     while (true)
     {
         __syncthreads();
@@ -1228,7 +1242,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
             uint32_t t = atomicAdd(&A.cursors[qcur], 1u), p = 0xFFFFFFFFu;
             for (int cls = cls_hi; cls >= cls_lo; --cls)
             {
-                const uint32_t cnt = A.cursors[16 + cls];
+                const uint32_t cnt = A.cursors[cbase + cls];
                 if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
                 t -= cnt;
             }
@@ -1267,7 +1281,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
                 fits = 16u * (size_t)(2u * WL::kNR) <= pool.per_wg;
                 if (fits) err = wc_attach(W, (const uint32_t*)(img + rl.hist), (const uint32_t*)(img + rl.zhist), (const uint32_t*)(img + rl.bst), F, rec.img_n, zmask, ctr, A.cursors + 96);
             }
-            else
+            else if constexpr (FALLBACK)
             {
                 const ImgLayout lay = img_layout(F, nbV, rec.img_n, rec.img_h);
                 const WcImg im{(const uint16_t*)(img + lay.loff), (const uint8_t*)(img + lay.llen), (const uint8_t*)(img + lay.comp),
@@ -1284,6 +1298,13 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
             {
                 for (int q = 0; q < 29; ++q) if (q != 22 && q != 23 && W.ph[q]) atomicAdd(&g_wstamp[q], W.ph[q]);
                 // LDS the pair needed at its worst plane, and at its worst plane from the third on (classes of 4 KiB)
+                if (p < 8192u)
+                {
+                    uint32_t mb = 0; for (uint32_t k = 0; k < F; ++k) { const uint32_t c = W.bst[k + 1u] - W.bst[k]; mb = c > mb ? c : mb; }
+                    g_wneed[4u * p] = rec.img_n; g_wneed[4u * p + 1u] = mb; g_wneed[4u * p + 2u] = err == 0 ? (uint32_t)W.ph[31] : 0xFFFFFFFFu;
+                    unsigned long long cyc = 0; for (int q = 0; q < 16; ++q) cyc += W.ph[q];
+                    g_wneed[4u * p + 3u] = (uint32_t)cyc;
+                }
                 if (err == 0)
                 {
                     unsigned long long c = W.ph[31] / 4096ull, c2 = W.ph[29] / 4096ull;
@@ -1299,8 +1320,18 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
         if (tid == 0) atomicAdd(&A.cursors[err == WC_BAIL ? 89 : 88], 1u);       // (diagnostic: pairs the record clipper took / handed on)
         if (err == WC_BAIL)
         {
-            __syncthreads();
-            clip_pair_general(Gn.sh, Gn.L, S, pool, wg, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
+            if constexpr (FALLBACK)
+            {
+                __syncthreads();
+                clip_pair_general(Gn.sh, Gn.L, S, pool, wg, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, horder, p, rec);
+            }
+            else if (tid == 0)
+            {
+                // to the large tier, first in its queue (class 12); its image is spent (rec.img_fmt is IMG_NONE by now)
+                pairs[p] = rec;
+                horder[(size_t)12 * n_pairs + atomicAdd(&A.cursors[16u + 12u], 1u)] = p;      // (horder: the large tier's table here)
+                atomicAdd(&A.cursors[146], 1u);
+            }
             continue;
         }
         if (err == 0 && rec.cv_bad != 0 && rec.ni != 0) err = SURTR_E_TOPOLOGY;       // a fragment with an invalid Convex
@@ -1319,6 +1350,26 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
     constexpr size_t kBytes = sizeof(WcLds) > sizeof(GenLds) ? sizeof(WcLds) : sizeof(GenLds);
     __shared__ alignas(16) unsigned char lds_raw[kBytes];
     clip_pairs_wave_body<WcLds, GenLds>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, order, horder, cls_hi, cls_lo, qcur, walk0);
+}
+
+// The small tier: the record images whose worst plane fits SURTR_WR_S units of LDS (k_prep_pairs predicts it from the band size and
+// the largest bucket), three workgroups per CU -- 12 waves per CU instead of 8 for a kernel that is bound by instruction issue and
+// dependent LDS round trips (measured in round 3 on a timing-only build: -17 % for the pairs it takes).  No general clipper
+// inside: 0 bytes of private scratch, the registers of the record clipper alone.
+#ifndef SURTR_WR_S
+#define SURTR_WR_S 2240u
+#define SURTR_WNL_S 2048u
+#endif
+typedef WcLdsT<SURTR_WR_S, SURTR_WNL_S> WcLdsS;
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_clip_pairs_rec(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ sorder,
+                                                         uint32_t* __restrict__ order, uint32_t walk0)
+{
+    __shared__ alignas(16) unsigned char lds_raw[sizeof(WcLdsS)];
+    clip_pairs_wave_body<WcLdsS, WcLdsS, false>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, sorder, order, 11, 0, 144u, walk0);
 }
 
 // The same with a whole CU's LDS for the record clipper (and the double-size topology for the general one it falls back to): the
@@ -2801,7 +2852,7 @@ int surtr_create(int device, surtr_ctx** out)
     }
     // (surtr_destroy releases whatever was created so far: no leak on a failure half-way)
     if (hipMalloc((void**)&ctx->d_counts, sizeof(surtr_counts)) != hipSuccess ||
-        hipMalloc((void**)&ctx->arena.cursors, 512) != hipSuccess ||
+        hipMalloc((void**)&ctx->arena.cursors, 1024) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming) != hipSuccess ||
@@ -2822,7 +2873,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->fs_big.base); free_dev(ctx->d_blk_big); free_dev(ctx->d_face_list);
     free_dev(ctx->d_pair_order); free_dev(ctx->d_face_group);
-    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder);
+    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder); free_dev(ctx->pool_rec.base);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_half) (void)hipEventDestroy(ctx->ev_half);
@@ -3060,7 +3111,7 @@ static int ensure_prep(surtr_ctx* ctx, uint32_t n_pairs, uint32_t n_wg)
     if (ctx->cap_order < n_pairs)
     {
         free_dev(ctx->d_order); ctx->d_order = nullptr;
-        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 48 * 4));      // three tables: clip order, pre-pass order, half clip order
+        HIPCHK(hipMalloc((void**)&ctx->d_order, (size_t)n_pairs * 64 * 4));      // four tables: clip order, pre-pass order, half clip order, small record tier
         ctx->cap_order = n_pairs;
     }
     const uint64_t full = (uint64_t)ctx->vmax * 16 + (uint64_t)ctx->hmax * 2;
@@ -3180,7 +3231,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     rc = ensure_prep(ctx, std::max(n_pairs, 1u), std::max(n_wg_prep, ctx->n_wg_prep));
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 512, st));
+    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 1024, st));
     HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
     HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
     const uint8_t* d_out = nullptr;
@@ -3239,6 +3290,28 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     uint32_t rec_maxn = SURTR_REC_MAXN;
     if (const char* e = getenv("SURTR_REC_MAXN")) rec_maxn = (uint32_t)atoi(e);
     rec_on |= (rec_maxn < 0xFFFFFFu ? rec_maxn : 0xFFFFFFu) << 8;
+    // the small tier of the record clipper: three workgroups per CU for the record images whose worst plane fits its LDS
+    // OFF by default.  Measured on configs[3] (MI355X, round 4): the small tier's kernel has 114 registers, no private scratch and
+    // 53 680 B of LDS (three workgroups per CU) and takes 2 400 of 3 335 pairs in 0.64 ms -- but the 900 heavy pairs left for the
+    // large tier then take 1.02 ms on their own (two or three 0.4 ms pairs per workgroup: no light pairs left to level the end),
+    // 1.66 ms for the two kernels one behind the other against 1.45 ms for the one kernel; 2.51 against 2.39 ms per step with
+    // three events in flight.  Side by side on two streams the event took 2.58 ms when the two grids happened to interleave
+    // and 2.98 ms when one filled the CUs first (SURTR_SMALL_CONC, timing only).  SURTR_SMALL=1 turns the tier on.
+    uint32_t small_cap = 0u;
+    if (const char* e = getenv("SURTR_SMALL")) { if (atoi(e) != 0 && wave_on && (rec_on & 1u)) small_cap = 16u * SURTR_WR_S; }
+    uint32_t n_wg_rec = 0;
+    if (small_cap)
+    {
+        n_wg_rec = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->hw_wg / 2u * 3u));
+        if (const char* e = getenv("SURTR_SMALL_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= 4096u) n_wg_rec = v; }
+        const size_t per = ((size_t)16u * 2u * SURTR_WR_S + 255u) & ~(size_t)255u;
+        if (!(ctx->pool_rec.base && ctx->pool_rec.per_wg >= per && ctx->n_wg_rec >= n_wg_rec))
+        {
+            free_dev(ctx->pool_rec.base); ctx->pool_rec.base = nullptr;
+            ctx->pool_rec.per_wg = per; ctx->pool_rec.CV = ctx->pool_rec.CH = ctx->pool_rec.VMAX = 0; ctx->n_wg_rec = n_wg_rec;
+            HIPCHK(hipMalloc((void**)&ctx->pool_rec.base, per * n_wg_rec));
+        }
+    }
     PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
     uint32_t wide_max = 4u * ctx->max_wg;
@@ -3247,11 +3320,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
@@ -3273,6 +3346,14 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // (measured on blocks of configs[3]: the record clipper wins once the pairs queue up -- 4 096 pairs 1.88 -> 1.65 ms, 2 048 pairs
     // 2.35 -> 2.30 ms for the event -- and loses when every pair has a workgroup to itself: 1 024 pairs 1.63 -> 1.69 ms, 512 pairs
     // 1.33 -> 1.45 ms; its loader sorts the band, which the general clipper's image copy does not have to)
+    hipStream_t st_rec = st2;
+    if (getenv("SURTR_SMALL_CONC")) st_rec = st3;      // (timing experiment only: the large tier then misses late hand-overs)
+    PROF_BEGIN_ON(12, st_rec);
+    if (n_pairs && wave_on && small_cap)
+        hipLaunchKernelGGL(k_clip_pairs_rec, dim3(n_wg_rec), dim3(SURTR_WG), 0, st_rec, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool_rec, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list,
+                           (const uint32_t*)(ctx->d_order + (size_t)32 * ctx->cap_order + (size_t)16 * n_pairs), ctx->d_order, walk0);
+    PROF_END_ON(12, st_rec);
     PROF_BEGIN_ON(11, st2);
     if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st2);
     if (n_pairs && wave_on)
@@ -3711,6 +3792,17 @@ int surtr_debug_stamps2(unsigned long long out[64], int reset)
     if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(z)); }
     return SURTR_OK;
 }
+int surtr_debug_wneed(uint32_t* out, uint32_t n_words)
+{
+#ifdef SURTR_STAMP
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wneed), sizeof(uint32_t) * std::min<uint32_t>(n_words, 4u * 8192u)) != hipSuccess) return SURTR_E_HIP;
+    return SURTR_OK;
+#else
+    (void)out; (void)n_words;
+    return SURTR_E_STATE;
+#endif
+}
+
 int surtr_debug_stamps_wave(unsigned long long out[64], int reset)
 {
 #ifdef SURTR_STAMP

@@ -52,6 +52,7 @@
 // Diagnostic build only (-DSURTR_STAMP): lane-0 cycles per phase
 #ifdef SURTR_STAMP
 __device__ unsigned long long g_wstamp[64];
+__device__ uint32_t g_wneed[4 * 8192];      // per pair: band vertices, largest bucket, LDS bytes needed at the worst plane, cycles
 #define WSTAMP_DECL unsigned long long ws_t0 = __builtin_readcyclecounter(), ws_t1
 // (accumulated in LDS, flushed once per pair by the kernel: a global atomic per phase would be what the stamps measure)
 #define WSTAMP(i) do { if (threadIdx.x == 0u) { ws_t1 = __builtin_readcyclecounter(); W.ph[i] += ws_t1 - ws_t0; ws_t0 = ws_t1; } } while (0)
@@ -520,15 +521,36 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         //      slot)), and the place of every kept cut point in the next plane's list. ----
         const uint32_t NI = nCo + nl;
         if (NI > 4095u) WC_RET(6);
-        if (4u * rtop + 8u * nCo + NI + (NI + 1u) / 2u + 64u > ltop) WC_RET(4);
+        // The originals a plane clips are normally copied into LDS (the "stage": 16 bytes each; the walks step through them).  The
+        // first planes of a band clip hundreds of them at once -- the stage of that one plane is what decides how much LDS a pair
+        // needs (scripts/wave_need.py: 42 bytes per vertex of the largest bucket).  When stage + lists would not fit, the plane
+        // works on the records where they are, in global memory (this XCD's L2: the item scan has just fetched them): its walk
+        // steps through originals pay an L2 round trip instead of an LDS one, and the pair keeps its place in a kernel with a
+        // smaller LDS area instead of being handed on.
+        // (only the kernels with less LDS than the regular one do this: there the alternative is to hand the pair on)
+        const bool gstage = LT::kNR < SURTR_WR && nCo != 0u && 4u * rtop + 8u * nCo + NI + (NI + 1u) / 2u + 7u * NI + 3u * nl + 128u > ltop;
+        if (4u * rtop + (gstage ? 0u : 8u * nCo) + NI + (NI + 1u) / 2u + 64u > ltop) WC_RET(4);
+        WCOUNT(26, gstage ? 1 : 0);
         // stage: this plane's originals in LDS (their records are final: every patch of an earlier plane is in)
-        const uint32_t stage = carve(8u * nCo) / 8u;      // first unit of the stage
-        auto stage_put = [&](uint32_t i, const WcW4& wr) { __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16); };
-        // where the record of a vertex that is in LDS sits: a cut point (pool, 8-byte units from the bottom) or an original of this
-        // plane (stage); t16_of: 16-bit word index of its tail
-        auto off_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 8u * (e - WC_MAXN) : 16u * (stage + (e - b0)); };
-        auto t16_of = [&](uint32_t e) -> uint32_t { return e >= WC_MAXN ? 4u * (e - WC_MAXN) + 3u : 8u * (stage + (e - b0)) + 7u; };
-        auto rec_of = [&](uint32_t e) -> WcRec { return wc_rec(B, off_of(e), e >= WC_MAXN); };
+        const uint32_t stage = gstage ? 0u : carve(8u * nCo) / 8u;      // first unit of the stage
+        auto stage_put = [&](uint32_t i, const WcW4& wr) { if (!gstage) __builtin_memcpy(__builtin_assume_aligned(B + 16u * (size_t)(stage + i), 16), &wr, 16); };
+        // the record of a vertex the plane works on: a cut point (pool, 8-byte units from the bottom of the LDS area) or an original of
+        // this plane (stage, or global memory); its tail (16 bits) is read and written on its own
+        auto rec_of = [&](uint32_t e) -> WcRec {
+            if (e >= WC_MAXN) return wc_rec(B, 8u * (e - WC_MAXN), true);
+            if (gstage) { const WcW4 wr = g.grec[e]; return WcRec{wr.a, wr.b, wr.c, wr.d}; }
+            return wc_rec(B, 16u * (stage + (e - b0)), false);
+        };
+        auto tail_ld = [&](uint32_t e) -> uint32_t {
+            if (e >= WC_MAXN) return wc_ld16(B, 4u * (e - WC_MAXN) + 3u);
+            if (gstage) { uint16_t t; __builtin_memcpy(&t, GB + 16u * (size_t)e + 14u, 2); return t; }
+            return wc_ld16(B, 8u * (stage + (e - b0)) + 7u);
+        };
+        auto tail_st = [&](uint32_t e, uint32_t v) {
+            if (e >= WC_MAXN) wc_st16(B, 4u * (e - WC_MAXN) + 3u, v);
+            else if (gstage) { const uint16_t t = (uint16_t)v; __builtin_memcpy(GB + 16u * (size_t)e + 14u, &t, 2); }
+            else wc_st16(B, 8u * (stage + (e - b0)) + 7u, v);
+        };
         const uint16_t* nin = W.nlist[cur]; uint16_t* nout = W.nlist[cur ^ 1u];
         auto clipped_id = [&](uint32_t i) -> uint32_t { return i < nCo ? b0 + i : (uint32_t)nin[i - nCo]; };
         const uint32_t cbase = carve(NI), ckm8 = 2u * carve((NI + 1u) / 2u);      // ckm8: byte index; 0x80 | kept neighbours (bit j = ring slot j) of a clipped item, 0 for a kept one
@@ -625,14 +647,14 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         auto kfn2 = [&](uint32_t i, uint32_t& aux) -> uint2 {
             const uint32_t id = clipped_id(i), km = wc_ld8(B, ckm8 + i);
             if (!(km & 0x80u)) { aux = id << 8; return make_uint2(0u, 0u); }
-            aux = km | (id << 8) | (((wc_ld16(B, t16_of(id)) >> 8) & 7u) << 24);
+            aux = km | (id << 8) | (((tail_ld(id) >> 8) & 7u) << 24);
             return make_uint2(1u, (uint32_t)__builtin_popcount(km & 0x7Fu));
         };
         wc_rr_place<2>(W, sc, NI, st2, kfn2, [&](uint32_t i, uint32_t xc, uint32_t xm, uint2 c, uint32_t aux) {
             const uint32_t km = aux & 0x7Fu, id = (aux >> 8) & 0xFFFFu, len = aux >> 24;
             if (!c.x) { nout[i - xc] = (uint16_t)id; return; }      // (a kept cut point: every original before it is clipped)
             wc_st16(B, cbase + i, xm);
-            wc_st16(B, t16_of(id), 0x8000u | (len << 12) | i);
+            tail_st(id, 0x8000u | (len << 12) | i);
             if (i >= nCo) { W.freel[fring(fpush + (xc - nCo))] = (uint16_t)(id - WC_MAXN); wc_st16(B, clist + (xc - nCo), i); }
             uint32_t t = xm;
             for (uint32_t m = km; m; m &= m - 1u, ++t) { wc_st16(B, src + t, i | ((uint32_t)__builtin_ctz(m) << 12)); wc_st16(B, srcid + t, id); }
