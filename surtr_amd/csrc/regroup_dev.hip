@@ -235,6 +235,40 @@ __global__ void k_rg_labels(uint32_t ne, const uint2* __restrict__ edges, uint32
     if (e < n_pieces) { const uint32_t l = lab[e], ll = lab[l]; if (ll < l) { atomicMin(&lab[e], ll); *changed = 1u; } }
 }
 
+// The label rounds to convergence in ONE launch: a single workgroup sweeps the edges and the pointer jumps round after round
+// (labels only decrease, so a round that changes nothing ends it; at most n_pieces + 8 rounds, as the host loop had) -- no
+// host round trip per round.  rounds_out: rounds run, or 0xFFFFFFFF when the bound was hit.
+#define RG_LABEL_THREADS 1024u
+__global__ __launch_bounds__(RG_LABEL_THREADS) void k_rg_labels_all(uint32_t ne, const uint2* __restrict__ edges, uint32_t n_pieces, uint32_t* __restrict__ lab,
+                                                                    uint32_t* __restrict__ rounds_out)
+{
+    __shared__ uint32_t changed[2];
+    const uint32_t tid = threadIdx.x, G = blockDim.x;
+    if (tid < 2u) changed[tid] = 0u;
+    __syncthreads();
+    uint32_t round = 0;
+    for (; round < n_pieces + 8u; ++round)
+    {
+        bool ch = false;
+        for (uint32_t e = tid; e < ne; e += G)
+        {
+            const uint32_t a = edges[e].x, b = edges[e].y;
+            const uint32_t la = lab[a], lb = lab[b], m = la < lb ? la : lb;
+            if (m < la) { atomicMin(&lab[a], m); ch = true; }
+            if (m < lb) { atomicMin(&lab[b], m); ch = true; }
+        }
+        __syncthreads();
+        for (uint32_t v = tid; v < n_pieces; v += G) { const uint32_t l = lab[v], ll = lab[l]; if (ll < l) { atomicMin(&lab[v], ll); ch = true; } }
+        if (ch) changed[round & 1u] = 1u;
+        __syncthreads();
+        const bool any = changed[round & 1u] != 0u;
+        if (tid == 0u) changed[(round + 1u) & 1u] = 0u;
+        __syncthreads();
+        if (!any) break;
+    }
+    if (tid == 0u) *rounds_out = round < n_pieces + 8u ? round + 1u : 0xFFFFFFFFu;
+}
+
 template <class T>
 struct Tmp
 {
@@ -342,20 +376,16 @@ extern "C" int surtr_event_regroup(surtr_ctx* ctx, int partial, uint32_t n_spher
         // min-label propagation with one pointer jump per round converges in a number of rounds bounded by the number of
         // pieces (labels only decrease); it runs until a round changes nothing -- a chain numbered against the grain takes as
         // many rounds as it is long, not 64
-        bool converged = ne == 0;
-        for (uint32_t round = 0; round < n + 8u && ne; ++round)
+        uint32_t rounds = 1u;
+        if (ne)
         {
-            HIPCHK(hipMemsetAsync(d_err + 2, 0, 4, st));
-            const uint32_t work = std::max(ne, n);
-            hipLaunchKernelGGL(k_rg_labels, dim3((work + 255) / 256), blk, 0, st, ne, d_edges.p, n, d_lab.p, d_err + 2);
-            uint32_t changed = 0;
-            HIPCHK(hipMemcpyAsync(&changed, d_err + 2, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (!changed) { converged = true; break; }
+            hipLaunchKernelGGL(k_rg_labels_all, dim3(1), dim3(SURTR_LANES == 1u ? 1u : RG_LABEL_THREADS)      /* (the emulation runs one thread per workgroup) */, 0, st, ne, d_edges.p, n, d_lab.p, d_err + 2);
+            HIPCHK(hipMemcpyAsync(&rounds, d_err + 2, 4, hipMemcpyDeviceToHost, st));
         }
-        if (!converged) return SURTR_E_STATE;      // (cannot happen: see the bound above; never hand out unconverged labels)
         HIPCHK(hipMemcpyAsync(lab.data(), d_lab.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipStreamSynchronize(st));        // (the one synchronisation of the label phase)
+        if (rounds == 0xFFFFFFFFu) return SURTR_E_STATE;      // (cannot happen: see the bound in the kernel; never hand out unconverged labels)
+        ctx->regroup_rounds = rounds;
     }
     // HandleConvexIsland's outcome: per compound, groups = label classes in order of their lowest piece; the first stays
     std::vector<std::set<int>> extra;

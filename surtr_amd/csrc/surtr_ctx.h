@@ -248,6 +248,7 @@ struct surtr_ctx
     char* sort_tmp = nullptr; size_t c_sort_tmp = 0;      // radix-sort scratch of the Morton sort
     uint32_t* d_from = nullptr; size_t c_from = 0;       // surtr_pieces_from_event: fragment list and offsets
     float upload_ms = 0.f; uint32_t upload_allocs = 0;   // surtr_upload_stats
+    uint32_t regroup_rounds = 0;                         // label rounds of the last surtr_event_regroup (one launch)
     uint64_t tot_mv = 0, tot_mh = 0;
     // cells
     uint32_t n_cells = 0, n_faces = 0, cap_pattern_faces = 0, cap_pattern_cells = 0;      // (capacities: set by surtr_build_cells only)
