@@ -32,5 +32,14 @@ for cap in (32768, 36864, 40960, 45056, 49152):
         adm = score + margin <= cap
         bad = (adm & ~fit).sum()
         print("      predicted + %4d <= cap: admitted %4d, of which %3d would not fit" % (margin, adm.sum(), bad))
+pb = (ctypes.c_ulonglong * 32)()
+L.surtr_debug_wplane(pb, 1)
+eng.fracture_event(0, 4096)
+L.surtr_debug_wplane(pb, 0)
+tot = sum(pb[2 * c + 1] for c in range(8))
+print("cutting planes by items per plane (originals the plane clips + alive cut points):")
+for c in range(8):
+    if pb[2 * c]:
+        print("   <= %4d items: %6d planes, %6.0f cycles per plane, %4.1f%% of the plane cycles" % (32 << c, pb[2 * c], pb[2 * c + 1] / pb[2 * c], 100.0 * pb[2 * c + 1] / max(tot, 1)))
 np.save("gpurun_out/wave_need.npy", d)
 eng.close()

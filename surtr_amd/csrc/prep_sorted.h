@@ -44,17 +44,21 @@ struct SortedRings
 
 // first plane that has the whole sphere on its cut side while every earlier plane has it on its kept side; 0xFF: undecided
 // (conservative margins: prepass_select, A0)
-__device__ __forceinline__ uint32_t ps_sphere_fc(const Shared& sh, const uint32_t F, const float4 sp)
+// k0: the first plane to look at (the enclosing sphere of the level above was wholly on the kept side of the planes before it);
+// kstop: the plane the test stopped at -- the first one the sphere is not wholly on the kept side of (F: none).
+__device__ __forceinline__ uint32_t ps_sphere_fc(const Shared& sh, const uint32_t F, const float4 sp, const uint32_t k0, uint32_t& kstop)
 {
     const float mag = fabsf(sp.x) + fabsf(sp.y) + fabsf(sp.z) + sp.w;
-    for (uint32_t k = 0; k < F; ++k)
+    for (uint32_t k = k0; k < F; ++k)
     {
         const float4 mk = sh.pmar[k];
         const float sk = plane_dist(sh.planes[k], sp.x, sp.y, sp.z);
         const float margin = sp.w * mk.x + mk.y + mk.z * mag;
+        kstop = k;
         if (sk > margin) return k;
         if (!(sk < -margin)) return 0xFFu;
     }
+    kstop = F;
     return 0xFFu;
 }
 
@@ -86,13 +90,13 @@ __device__ __forceinline__ void ps_append2(uint2* list, uint32_t* counter, bool 
 // not fit goes to vfc_g), then `ubw` words "set bits before this word" and `ubw` words of one bit per group ("undecided").
 // On return it holds what the emits read: bmask (one 64-bit word per 64 vertices, first half) and bblk (one pair per 64
 // vertices, second half; x: kept vertices before the block, y: their ring entries), built from the kept list.
-// vfc_g, needy, und, klist, walks: global scratch (V entries each at most; und: one per group).
+// vfc_g, needy, und, klist, walks: global scratch (V entries each at most; und: one per group); kst: global scratch, one byte per group.
 // Requires in.nv < 65535, ceil(in.nv / SURTR_SB) <= 32 * ubw, in.nv <= 64 * NB, the sorted copy.
 // Leaves: klist[0 .. n) = (vertex | (fc | 0x80: in a plane before fc) << 24, sorted index | ring length << 16), in no order;
 // sh.hist / zhist raw (prepass_finish_hist); sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7, sh.flagBad.
 template <uint32_t NB, uint32_t UBW>
 __device__ __attribute__((always_inline)) inline void prepass_select_sorted(const SolidIn in, const SortedRings sr, const uint32_t F, Shared& sh,
-                                                                            unsigned char* lbuf, uint8_t* vfc_g, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
+                                                                            unsigned char* lbuf, uint8_t* vfc_g, uint8_t* kst, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
                                                                             uint32_t& n_out, uint32_t& hsum_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
@@ -124,38 +128,44 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     //      A0 is done.  A decided sphere only counts its vertices (all dropped with one fc); an undecided group sets its bit. ----
     const uint32_t nsb = (V + SURTR_SB - 1u) / SURTR_SB;
     const uint32_t nb2 = (nsb + SURTR_SPH_FAN - 1u) / SURTR_SPH_FAN, nb3 = (nb2 + SURTR_SPH_FAN - 1u) / SURTR_SPH_FAN;
-    uint16_t* list2 = (uint16_t*)lbuf;                 // undecided level-2 spheres (nb2 of them at most)
-    uint16_t* list3 = list2 + nb2 + 8u;                // undecided level-3 spheres
+    // (entries: sphere | plane its test stopped at << 16 -- the level below starts its own tests there)
+    uint32_t* list2 = (uint32_t*)lbuf;                 // undecided level-2 spheres (nb2 of them at most)
+    uint32_t* list3 = list2 + nb2 + 8u;                // undecided level-3 spheres
     auto verts_in = [&](uint32_t g0, uint32_t g1) -> uint32_t {      // vertices of groups [g0, g1)
         const uint32_t a = g0 * SURTR_SB, b = g1 * SURTR_SB;
         return (b < V ? b : V) - (a < V ? a : V);
     };
     for (uint32_t s3 = tid; s3 < nb3; s3 += G)
     {
-        const uint32_t f = ps_sphere_fc(sh, F, sr.bsph3[s3]);
+        uint32_t ks = 0;
+        const uint32_t f = ps_sphere_fc(sh, F, sr.bsph3[s3], 0u, ks);
         const uint32_t g0 = s3 * SURTR_SPH_FAN * SURTR_SPH_FAN;
         if (f != 0xFFu) atomicAdd(&sh.hist[f], verts_in(g0, g0 + SURTR_SPH_FAN * SURTR_SPH_FAN));
-        else list3[atomicAdd(&sh.misc[1], 1u)] = (uint16_t)s3;
+        else list3[atomicAdd(&sh.misc[1], 1u)] = s3 | (ks << 16);
     }
     __syncthreads();
     const uint32_t nU3 = sh.misc[1];
     for (uint32_t t = tid; t < nU3 * SURTR_SPH_FAN; t += G)
     {
-        const uint32_t s2 = (uint32_t)list3[t / SURTR_SPH_FAN] * SURTR_SPH_FAN + t % SURTR_SPH_FAN;
+        const uint32_t e3 = list3[t / SURTR_SPH_FAN];
+        const uint32_t s2 = (e3 & 0xFFFFu) * SURTR_SPH_FAN + t % SURTR_SPH_FAN;
         if (s2 >= nb2) continue;
-        const uint32_t f = ps_sphere_fc(sh, F, sr.bsph2[s2]);
+        uint32_t ks = 0;
+        const uint32_t f = ps_sphere_fc(sh, F, sr.bsph2[s2], e3 >> 16, ks);
         if (f != 0xFFu) atomicAdd(&sh.hist[f], verts_in(s2 * SURTR_SPH_FAN, s2 * SURTR_SPH_FAN + SURTR_SPH_FAN));
-        else list2[atomicAdd(&sh.misc[2], 1u)] = (uint16_t)s2;
+        else list2[atomicAdd(&sh.misc[2], 1u)] = s2 | (ks << 16);
     }
     __syncthreads();
     const uint32_t nU2 = sh.misc[2];
     for (uint32_t t = tid; t < nU2 * SURTR_SPH_FAN; t += G)
     {
-        const uint32_t sb = (uint32_t)list2[t / SURTR_SPH_FAN] * SURTR_SPH_FAN + t % SURTR_SPH_FAN;
+        const uint32_t e2 = list2[t / SURTR_SPH_FAN];
+        const uint32_t sb = (e2 & 0xFFFFu) * SURTR_SPH_FAN + t % SURTR_SPH_FAN;
         if (sb >= nsb) continue;
-        const uint32_t f = ps_sphere_fc(sh, F, in.bsph[sb]);
+        uint32_t ks = 0;
+        const uint32_t f = ps_sphere_fc(sh, F, in.bsph[sb], e2 >> 16, ks);
         if (f != 0xFFu) atomicAdd(&sh.hist[f], verts_in(sb, sb + 1u));
-        else atomicOr(&ub[sb >> 5], 1u << (sb & 31u));
+        else { atomicOr(&ub[sb >> 5], 1u << (sb & 31u)); kst[sb] = (uint8_t)ks; }
     }
     __syncthreads();
     // the undecided groups in ascending (Morton) order, from the bits: und[rank] = group, pre[q] = set bits before word q.  The
@@ -175,7 +185,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
             {
                 uint32_t at = carry + woff + inc - c;
                 pre[q] = at;
-                for (uint32_t m = ub[q]; m; m &= m - 1u) und[at++] = 32u * q + (uint32_t)__builtin_ctz(m);
+                for (uint32_t m = ub[q]; m; m &= m - 1u) { const uint32_t g = 32u * q + (uint32_t)__builtin_ctz(m); und[at++] = g | ((uint32_t)kst[g] << 24); }
             }
             carry += tot;
             __syncthreads();
@@ -198,13 +208,20 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     {
         const uint32_t sub = wb * GPW + l / SURTR_SB;
         const bool okg = sub < nUnd;
-        const uint32_t i = (okg ? und[sub] : 0u) * SURTR_SB + (l % SURTR_SB);
+        const uint32_t ue = okg ? und[sub] : 0xFF000000u;
+        const uint32_t i = (ue & 0xFFFFFFu) * SURTR_SB + (l % SURTR_SB);
         const bool valid = okg && i < V;
         const float4 pr = in.posr_s[valid ? i : 0u];
         const float mag = fabsf(pr.x) + fabsf(pr.y) + fabsf(pr.z);
+        // the planes before the one the group's sphere test stopped at have the whole group, balls included, strictly on their
+        // kept side: they clip nothing here, hold no vertex, and leave the ball test as it is -- the loop starts at the earliest
+        // such plane of the wave-load's groups (neighbours in space: the list is in Morton order)
+        uint32_t kmin = 0xFFu;
+#pragma unroll
+        for (uint32_t q = 0; q < GPW; ++q) { const uint32_t kq = lane_bcast(ue >> 24, q * SURTR_SB); kmin = kq < kmin ? kq : kmin; }
         uint32_t f = PS_NEVER, z = 0u;
         bool done = !valid, clear = true;
-        for (uint32_t k = 0; k < F; ++k)
+        for (uint32_t k = kmin; k < F; ++k)
         {
             if (__all(done)) break;
             const float4 mk = sh.pmar[k];

@@ -842,7 +842,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         if (sorted_sel)
         {
             const SortedRings sr{P.mrow_s + m0, P.miperm + m0, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
-            prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, needy, und, klist, walks, n, hsum);
+            prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, fcb, needy, und, klist, walks, n, hsum);
         }
         else prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
@@ -3792,6 +3792,18 @@ int surtr_debug_stamps2(unsigned long long out[64], int reset)
     if (reset) { unsigned long long z[64] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp2), z, sizeof(z)); }
     return SURTR_OK;
 }
+int surtr_debug_wplane(unsigned long long out[32], int reset)
+{
+#ifdef SURTR_STAMP
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wplane), sizeof(unsigned long long) * 32) != hipSuccess) return SURTR_E_HIP;
+    if (reset) { unsigned long long z[32] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wplane), z, sizeof(z)); }
+    return SURTR_OK;
+#else
+    (void)out; (void)reset;
+    return SURTR_E_STATE;
+#endif
+}
+
 int surtr_debug_wneed(uint32_t* out, uint32_t n_words)
 {
 #ifdef SURTR_STAMP

@@ -52,6 +52,7 @@
 // Diagnostic build only (-DSURTR_STAMP): lane-0 cycles per phase
 #ifdef SURTR_STAMP
 __device__ unsigned long long g_wstamp[64];
+__device__ unsigned long long g_wplane[32];      // per class of items per plane (<= 32, 64, 128, 256, 512, 1024, 2048, more): planes, lane-0 cycles
 __device__ uint32_t g_wneed[4 * 8192];      // per pair: band vertices, largest bucket, LDS bytes needed at the worst plane, cycles
 #define WSTAMP_DECL unsigned long long ws_t0 = __builtin_readcyclecounter(), ws_t1
 // (accumulated in LDS, flushed once per pair by the kernel: a global atomic per phase would be what the stamps measure)
@@ -507,6 +508,9 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
     WSTAMP_DECL;
     for (uint32_t k = 0; k < F; ++k)
     {
+#ifdef SURTR_STAMP
+        const unsigned long long pl_t0 = __builtin_readcyclecounter();
+#endif
         if ((zmask >> k) & 1ull) WC_RET(3);          // a live vertex lies in this plane: the reference's general relink
         const float4 pl = W.planes[k];
         // originals this plane clips: ids [b0, b1), in order; later buckets are kept, earlier ones gone
@@ -824,6 +828,9 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         // next plane's scan is through its barrier)
         nLive = nLive - nC + M; nl = keepn + M;
         WSTAMP(9);
+#ifdef SURTR_STAMP
+        if (tid == 0u) { int c = 0; while (c < 7 && (32u << c) < NI) ++c; atomicAdd(&g_wplane[2 * c], 1ull); atomicAdd(&g_wplane[2 * c + 1], __builtin_readcyclecounter() - pl_t0); }
+#endif
         if (nLive + dropAlive < 4u) { nLive = 0; break; }                          // (:497-499)
     }
     __syncthreads();
