@@ -381,13 +381,14 @@ std::vector<uint32_t> sphere_offsets(uint32_t n, const uint32_t* vo)
 // What the event sizes its scratch from, and whether the half-size clip kernel is worth launching.
 void set_piece_stats(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const uint32_t* mho, const uint32_t* cvo, const uint32_t* cho)
 {
-    uint32_t vmax = 0, hmax = 0, cvmax = 0, chmax = 0, small = 0;
+    uint32_t vmax = 0, hmax = 0, cvmax = 0, chmax = 0, small = 0, vmin = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < n; ++i)
     {
-        vmax = std::max(vmax, mvo[i + 1] - mvo[i]); hmax = std::max(hmax, mho[i + 1] - mho[i]);
+        vmax = std::max(vmax, mvo[i + 1] - mvo[i]); vmin = std::min(vmin, mvo[i + 1] - mvo[i]); hmax = std::max(hmax, mho[i + 1] - mho[i]);
         cvmax = std::max(cvmax, cvo[i + 1] - cvo[i]); chmax = std::max(chmax, cho[i + 1] - cho[i]);
         if (surtr_fits_half((mvo[i + 1] - mvo[i]) / 4u, (mho[i + 1] - mho[i]) / 4u)) ++small;      // what a cell keeps of it is likely light
     }
+    ctx->vmin = n ? vmin : 0u;
     ctx->n_pieces = n; ctx->vmax = std::max(vmax, cvmax); ctx->hmax = std::max(hmax, chmax); ctx->cvmax = cvmax; ctx->chmax = chmax;
     ctx->tot_mv = mvo[n]; ctx->tot_mh = mho[n]; ctx->pair_order_count = 0;
     ctx->half_on = 4ull * small >= 3ull * n;

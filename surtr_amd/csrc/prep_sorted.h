@@ -344,10 +344,14 @@ __device__ __forceinline__ uint32_t ps_newid(const unsigned long long* bmask, co
 // without its sweep over every 64-vertex block of the piece and without its plane loop (the first clipping planes are in the list;
 // only a vertex that lies in a plane before its fc is evaluated again, for sh.nzero).  scan: global, ceil(n / 64) + 2 pairs.
 __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const SolidIn in, const uint32_t F, Shared& sh, Topo<InLds>& T, const unsigned long long* bmask,
-                                                                         const uint2* bblk, const uint2* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum)
+                                                                         const uint2* bblk, const uint2* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum, uint32_t& maxb_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
     STAMP_DECL;
+    // band vertices per first clipping plane (sh.pw: the sphere margins are done with): the largest bucket is what the record
+    // clipper's LDS need at its worst plane follows
+    for (uint32_t k = tid; k <= F; k += G) sh.pw[k] = 0u;
+    __syncthreads();
     for (uint32_t t = tid; t < n; t += G)
     {
         const uint2 ke = klist[t];
@@ -356,7 +360,7 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const S
         orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
         T.llen[id] = (uint8_t)((ke.y >> 16) < 255u ? (ke.y >> 16) : in.llen[v]);
         T.fc[id] = (uint8_t)(f == PS_NEVER ? SURTR_NEVER : f);
-        if (f != PS_NEVER) atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u));
+        if (f != PS_NEVER) { atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u)); if (f < F) atomicAdd(&sh.pw[f], 1u); }
         if (byte & 0x80u)
         {
             const float4 pr = in.posr_s[ke.y & 0xFFFFu];
@@ -401,6 +405,9 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const S
     }
     STAMP(2);
     __syncthreads();
+    uint32_t maxb = 0;
+    for (uint32_t k = 0; k < F; ++k) maxb = sh.pw[k] > maxb ? sh.pw[k] : maxb;
+    maxb_out = maxb;
     T.nS = n; T.nLive = n; T.hUsed = hsum;
 }
 

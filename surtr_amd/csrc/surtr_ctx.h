@@ -222,6 +222,9 @@ struct surtr_ctx
     uint32_t hw_wg = 512, hw_wg_faces = 1024, hw_wg_prep = 1792, hw_wg_big = 48, budget_vmax = 0xFFFFFFFFu, budget_hmax = 0xFFFFFFFFu;
     uint32_t max_wg = 512, max_wg_faces = 1024, max_wg_small = 2048, max_wg_prep = 1792, max_wg_half = 1024;
     ScratchPool pool_rec{}; uint32_t n_wg_rec = 0;          // k_clip_pairs_rec: positions of the cut points only
+    uint32_t* d_hlist = nullptr; uint32_t cap_hlist = 0;    // hand-over list of the split arrangement (k_clip_pairs_main -> k_clip_pairs_catch)
+    uint32_t n_wg_catch = 128;                              // workgroups of k_clip_pairs_catch (at most; scratch slots are reserved for them)
+    uint32_t vmin = 0;                                      // smallest Mesh of the resident pieces
     ScratchPool pool_half{}; uint32_t n_wg_half = 0;       // k_clip_pairs_half: scratch for the half-size LDS topology only
     // Light pairs go to k_clip_pairs_half only when they are most of the event (small pieces: refracture).  Beside a
     // full k_clip_pairs a third kernel costs more than it gains (configs[3]: +0.2 ms even when its workgroups exit at

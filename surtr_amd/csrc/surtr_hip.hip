@@ -759,7 +759,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                          uint32_t n_pairs, const PrepPool& pool, const Arena& A, const ImgArena& IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t small_cap)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t small_cap, uint32_t heavy_need)
 {
     // order[c * n_pairs + i]: the pairs of cost class c (0 light .. 15 heavy); k_clip_pairs starts with the heavy
     // ones, so that a pair that takes milliseconds (one that outgrows the LDS topology) is not left for the end
@@ -902,7 +902,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             if (tid < 4u) sh.cutmask[tid] = 0u;
             __syncthreads();
             // (also counts sh.nzero, collects sh.cutmask)
-            if (sorted_sel) prepass_emit_klist(min, F, sh, T, bmask, bblk, klist, orig, (uint2*)und, n, hsum);
+            if (sorted_sel) prepass_emit_klist(min, F, sh, T, bmask, bblk, klist, orig, (uint2*)und, n, hsum, maxb_rec);
             else prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);
             STAMP(74);
             prepass_finish_hist(F, sh);
@@ -928,6 +928,10 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
                                                  __builtin_popcount(sh.cutmask[2]) + __builtin_popcount(sh.cutmask[3]));
                 const uint32_t cost = (41u * ncut + n / 40u) / 110u;
                 cls = !fits_with_room(n, hsum, capV, SURTR_LH) ? 14u : 1u + (cost < 11u ? cost : 11u);
+                // split arrangement (heavy_need != 0): a band the record clipper will run out of LDS on (its need at the worst plane
+                // follows the band size and the largest bucket: scripts/wave_need.py) would be handed on after a plane or two and then
+                // be the slowest task of the catcher -- it goes to the double-size general clipper (k_clip_pairs_big) from the start
+                if (cls < 12u && heavy_need != 0u && sorted_sel && (515u * n + 4185u * maxb_rec) / 100u + 393u > heavy_need) cls = 14u;
                 // a band vertex lies in a plane: the record clipper hands the pair to the general clipper, which takes longer --
                 // such pairs go first (the top regular class), not into the tail of the queue
                 if (cls < 12u && fmt == IMG_NARROW) { bool inplane = false; for (uint32_t k = 0; k < F; ++k) if (sh.nzero[k] != 0u) inplane = true; if (inplane) cls = 12u; }
@@ -970,12 +974,12 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap, uint32_t heavy_need)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
     unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
-    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap, heavy_need);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -986,12 +990,12 @@ __global__ __launch_bounds__(SURTR_WG_WIDE) void k_prep_pairs_wide(Pieces P, con
                                                          uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
                                                          PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
                                                          uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
-                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap)
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap, uint32_t heavy_need)
 {
     __shared__ Shared sh;
     __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
     unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
-    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap);
+    prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap, heavy_need);
 }
 
 // -------------------------------------------------------------- k_clip_pairs
@@ -1217,13 +1221,14 @@ struct GenLdsBig { Shared sh; LdsTopoBig L; };
 // FALLBACK = false: the small tier (k_clip_pairs_rec) -- record images only, no general clipper in the kernel (its LDS and registers
 // are the record clipper's alone: three workgroups per CU); a pair it gives up on goes to class 12 of the large tier's table,
 // whose kernel runs behind this one.
-template <class WL, class GL, bool FALLBACK = true>
+template <class WL, class GL, bool FALLBACK = true, bool OLD_IMAGES = FALLBACK>
 __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_body(unsigned char* lds_raw, uint32_t wg, const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
                                                          const ScratchPool& pool, const Arena& A, const ImgArena& IA, PairRec* __restrict__ pairs,
                                                          const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
-                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0)
+                                                         uint32_t* __restrict__ horder, int cls_hi, int cls_lo, uint32_t qcur, uint32_t walk0,
+                                                         uint32_t* __restrict__ hlist = nullptr, uint32_t cbase_arg = 0u)
 {
     WL& W = *reinterpret_cast<WL*>(lds_raw);
     GL& Gn = *reinterpret_cast<GL*>(lds_raw);
@@ -1233,7 +1238,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
     char* slot = pool.base + (size_t)wg * pool.per_wg;
     Scratch S{};
     if (FALLBACK) S = carve(pool, wg);
-    const uint32_t cbase = FALLBACK ? 16u : 128u;       // class counts of the table this kernel pulls from
+    const uint32_t cbase = cbase_arg ? cbase_arg : (FALLBACK ? 16u : 128u);       // class counts of the table this kernel pulls from
     while (true)
     {
         __syncthreads();
@@ -1281,7 +1286,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
                 fits = 16u * (size_t)(2u * WL::kNR) <= pool.per_wg;
                 if (fits) err = wc_attach(W, (const uint32_t*)(img + rl.hist), (const uint32_t*)(img + rl.zhist), (const uint32_t*)(img + rl.bst), F, rec.img_n, zmask, ctr, A.cursors + 96);
             }
-            else if constexpr (FALLBACK)
+            else if constexpr (OLD_IMAGES)
             {
                 const ImgLayout lay = img_layout(F, nbV, rec.img_n, rec.img_h);
                 const WcImg im{(const uint16_t*)(img + lay.loff), (const uint8_t*)(img + lay.llen), (const uint8_t*)(img + lay.comp),
@@ -1327,10 +1332,20 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
             }
             else if (tid == 0)
             {
-                // to the large tier, first in its queue (class 12); its image is spent (rec.img_fmt is IMG_NONE by now)
-                pairs[p] = rec;
-                horder[(size_t)12 * n_pairs + atomicAdd(&A.cursors[16u + 12u], 1u)] = p;      // (horder: the large tier's table here)
-                atomicAdd(&A.cursors[146], 1u);
+                pairs[p] = rec;          // (a record image is spent: rec.img_fmt is IMG_NONE by now; an old image is as it was)
+                if (hlist != nullptr)
+                {
+                    // to the catcher that runs beside this kernel (k_clip_pairs_catch): a slot of its list, filled with one atomic
+                    // so that whoever polls the slot sees either nothing or the pair
+                    __threadfence();
+                    atomicExch(&hlist[atomicAdd(&A.cursors[146], 1u)], p);
+                }
+                else
+                {
+                    // to the large tier, first in its queue (class 12), whose kernel is launched behind this one
+                    horder[(size_t)12 * n_pairs + atomicAdd(&A.cursors[16u + 12u], 1u)] = p;      // (horder: the large tier's table here)
+                    atomicAdd(&A.cursors[146], 1u);
+                }
             }
             continue;
         }
@@ -1338,6 +1353,8 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
         if (err != 0) { rec.status = (uint32_t)err; rec.ni = 0; if (tid == 0) pair_failed(A, err); }
         if (tid == 0) pairs[p] = rec;
     }
+    // the catcher stops polling when every workgroup of this kernel has said so (after its last hand-over)
+    if (!FALLBACK && hlist != nullptr && tid == 0) { __threadfence(); atomicAdd(&A.cursors[148], 1u); }
 }
 
 __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_wave(Pieces P, const float4* __restrict__ planes,
@@ -1360,8 +1377,14 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
 #define SURTR_WR_S 2240u
 #define SURTR_WNL_S 2048u
 #endif
-typedef WcLdsT<SURTR_WR_S, SURTR_WNL_S> WcLdsS;
-__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_clip_pairs_rec(Pieces P, const float4* __restrict__ planes,
+#ifndef SURTR_S_THREADS
+#define SURTR_S_THREADS SURTR_WG
+#endif
+#ifndef SURTR_S_WAVES_EU
+#define SURTR_S_WAVES_EU 3
+#endif
+typedef WcLdsT<SURTR_WR_S, SURTR_WNL_S, (SURTR_S_THREADS / SURTR_LANES > SURTR_NWAVE ? SURTR_S_THREADS / SURTR_LANES : SURTR_NWAVE)> WcLdsS;
+__global__ __launch_bounds__(SURTR_S_THREADS) __attribute__((amdgpu_waves_per_eu(SURTR_S_WAVES_EU, 4))) void k_clip_pairs_rec(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
                                                          ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
@@ -1370,6 +1393,93 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(3, 4))
 {
     __shared__ alignas(16) unsigned char lds_raw[sizeof(WcLdsS)];
     clip_pairs_wave_body<WcLdsS, WcLdsS, false>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, sorder, order, 11, 0, 144u, walk0);
+}
+
+// ---- The split arrangement (round 4): the regular pairs on a kernel that holds the record clipper ALONE, everything else beside it.
+// k_clip_pairs_wave carries the general clipper for the 2 % of its pairs that need it, and pays for it on every pair: 256 registers,
+// 1.9 KB of private scratch per lane.  The same pairs on the record clipper alone (114 registers, no scratch, the same LDS and
+// occupancy) take 1.12 instead of 1.40 ms on configs[3], 1.01 ms with 512 threads per pair (the planes of a heavy band hold a
+// thousand items and more).  So: k_clip_pairs_main takes cost classes 11..0 (record images and old images alike) and hands what
+// it cannot finish to k_clip_pairs_catch -- the general clipper on a few workgroups that run BESIDE it on another stream: they
+// start with the pairs k_prep_pairs knows to be irregular (classes 13..12), then poll the hand-over list until every workgroup
+// of the main kernel has signed off.  No later launch, no tail of its own.
+#ifndef SURTR_MAIN_THREADS
+#define SURTR_MAIN_THREADS (2u * SURTR_WG)
+#endif
+#ifndef SURTR_WR_MAIN
+#define SURTR_WR_MAIN 3072u       // (a plane that needs more stages its originals in global memory: the lists get the room instead)
+#define SURTR_WNL_MAIN 3584u
+#endif
+typedef WcLdsT<SURTR_WR_MAIN, SURTR_WNL_MAIN, (SURTR_MAIN_THREADS / SURTR_LANES > SURTR_NWAVE ? SURTR_MAIN_THREADS / SURTR_LANES : SURTR_NWAVE), true> WcLdsMain;
+// (two workgroups of 512 threads per CU = four waves per SIMD: at most 128 registers)
+__global__ __launch_bounds__(SURTR_MAIN_THREADS) __attribute__((amdgpu_waves_per_eu(SURTR_MAIN_THREADS > SURTR_WG ? 4 : 2, 4))) void k_clip_pairs_main(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ hlist, uint32_t walk0)
+{
+    __shared__ alignas(16) unsigned char lds_raw[sizeof(WcLdsMain)];
+    clip_pairs_wave_body<WcLdsMain, WcLdsMain, false, true>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, order, nullptr, 11, 0, 4u, walk0, hlist, 16u);
+}
+
+// The catcher: see above.  n_main: workgroups of k_clip_pairs_main (0: none was launched).  Its workgroups use the scratch slots
+// from wg_base on.  A workgroup that has waited a very long time for a slot gives up with SURTR_E_STATE rather than spin for ever.
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_catch(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs,
+                                                         ScratchPool pool, uint32_t wg_base, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
+                                                         const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
+                                                         uint32_t* __restrict__ hlist, uint32_t hcap, uint32_t n_main)
+{
+    __shared__ Shared sh;
+    __shared__ LdsTopo L;
+    const uint32_t tid = threadIdx.x, wg = wg_base + blockIdx.x;
+    Scratch S = carve(pool, wg);
+    bool own = true;
+    while (true)
+    {
+        __syncthreads();
+        if (tid == 0)
+        {
+            uint32_t p = 0xFFFFFFFFu;
+            if (own)
+            {
+                uint32_t t = atomicAdd(&A.cursors[150], 1u);
+                for (int cls = 13; cls >= 12; --cls)
+                {
+                    const uint32_t cnt = A.cursors[16 + cls];
+                    if (t < cnt) { p = order[(size_t)cls * n_pairs + t]; break; }
+                    t -= cnt;
+                }
+            }
+            if (p == 0xFFFFFFFFu)
+            {
+                own = false;
+                const uint32_t t = atomicAdd(&A.cursors[149], 1u);          // this workgroup's slot of the hand-over list
+                for (uint32_t spin = 0; t < hcap; ++spin)
+                {
+                    const uint32_t v = atomicAdd(&hlist[t], 0u);
+                    if (v != 0xFFFFFFFFu) { p = v; break; }
+                    if (atomicAdd(&A.cursors[148], 0u) >= n_main && atomicAdd(&A.cursors[146], 0u) <= t) break;      // nobody will fill it
+                    if (spin > (1u << 22)) { atomicMax(&A.cursors[5], (uint32_t)SURTR_E_STATE); break; }
+                    __builtin_amdgcn_s_sleep(32);
+                }
+            }
+            sh.misc[7] = p;
+            sh.misc[6] = own ? 1u : 0u;
+        }
+        __syncthreads();
+        const uint32_t p = sh.misc[7];
+        own = sh.misc[6] != 0u;
+        if (p >= n_pairs) break;
+        PairRec rec = pairs[p];
+        if (rec.cv_n == 0 || rec.status != 0) continue;
+        if (rec.img_fmt == IMG_EMPTY) continue;
+        if (rec.img_fmt == IMG_REC) rec.img_fmt = IMG_NONE;
+        if (tid == 0) atomicAdd(&A.cursors[94], 1u);      // (diagnostic, surtr_queue_stats: pairs the catcher clipped)
+        clip_pair_general(sh, L, S, pool, wg, P, planes, plane_off, cell_begin, A, IA, pairs, pair_list, (uint32_t*)nullptr, p, rec);
+    }
 }
 
 // The same with a whole CU's LDS for the record clipper (and the double-size topology for the general one it falls back to): the
@@ -2873,7 +2983,7 @@ void surtr_destroy(surtr_ctx* ctx)
     free_dev(ctx->pool.base); free_dev(ctx->pool_small.base); free_dev(ctx->pool_half.base); free_dev(ctx->fs.base); free_dev(ctx->d_blk);
     free_dev(ctx->fs_big.base); free_dev(ctx->d_blk_big); free_dev(ctx->d_face_list);
     free_dev(ctx->d_pair_order); free_dev(ctx->d_face_group);
-    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder); free_dev(ctx->pool_rec.base);
+    free_dev(ctx->prep.base); free_dev(ctx->img.base); free_dev(ctx->d_order); free_dev(ctx->d_forder); free_dev(ctx->pool_rec.base); free_dev(ctx->d_hlist);
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_half) (void)hipEventDestroy(ctx->ev_half);
@@ -3217,7 +3327,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     const uint32_t max_wg = ctx->max_wg;
     const uint32_t n_wg = std::max(1u, std::min(std::max(n_pairs, 1u), max_wg));
     // scratch slots [0, max_wg) belong to k_clip_pairs, the n_wg_big after them to k_clip_pairs_big
-    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, max_wg + ctx->n_wg_big);
+    // scratch slots [0, max_wg) belong to the Mesh clip's main kernel, the n_wg_big after them to k_clip_pairs_big, then k_clip_pairs_catch's
+    int rc = ensure_scratch(ctx, ctx->vmax, ctx->hmax, max_wg + ctx->n_wg_big + ctx->n_wg_catch);
     if (rc) return rc;
     const uint32_t n_wg_small = std::max(1u, std::min(std::max(n_pairs, 1u), ctx->max_wg_small));
     rc = ensure_scratch_small(ctx, std::max(ctx->max_wg_small, ctx->n_wg_small));
@@ -3299,6 +3410,28 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // and 2.98 ms when one filled the CUs first (SURTR_SMALL_CONC, timing only).  SURTR_SMALL=1 turns the tier on.
     uint32_t small_cap = 0u;
     if (const char* e = getenv("SURTR_SMALL")) { if (atoi(e) != 0 && wave_on && (rec_on & 1u)) small_cap = 16u * SURTR_WR_S; }
+    // the split arrangement (k_clip_pairs_main + k_clip_pairs_catch, see there) for events whose every pair gets an image from
+    // k_prep_pairs: pieces of fewer than SURTR_PREP_MINV vertices are pre-passed by the general clipper itself, which only the
+    // one-kernel arrangement has on every workgroup
+    bool split_on = wave_on && !small_cap && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= ctx->prep.VMAX;
+    if (const char* e = getenv("SURTR_SPLIT")) split_on = split_on && atoi(e) != 0;
+    // (measured on configs[3]: 16 .. 32 workgroups end with the main kernel -- 35 pairs with a vertex in a plane + a hand-over or two;
+    //  64 and more take LDS from it: 2.50 / 2.50 / 2.56 ms per event with 16 / 32 / 64)
+    uint32_t n_catch = std::min(std::min(ctx->n_wg_catch, 32u), std::max(n_pairs, 1u));
+    if (const char* e = getenv("SURTR_CATCH_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_catch) n_catch = v; }
+    const uint32_t hcap = n_pairs + 4096u;
+    uint32_t heavy_need = 0u;      // (off: k_clip_pairs_big takes 2 x its grid of such pairs and no more -- the rest would land on the catcher)
+    if (const char* e = getenv("SURTR_HEAVY_NEED")) { if (split_on) heavy_need = (uint32_t)atoi(e); }
+    if (split_on)
+    {
+        if (ctx->cap_hlist < hcap)
+        {
+            free_dev(ctx->d_hlist); ctx->d_hlist = nullptr;
+            HIPCHK(hipMalloc((void**)&ctx->d_hlist, (size_t)hcap * 4));
+            ctx->cap_hlist = hcap;
+        }
+        HIPCHK(hipMemsetAsync(ctx->d_hlist, 0xFF, (size_t)hcap * 4, st));
+    }
     uint32_t n_wg_rec = 0;
     if (small_cap)
     {
@@ -3320,11 +3453,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
@@ -3350,13 +3483,18 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (getenv("SURTR_SMALL_CONC")) st_rec = st3;      // (timing experiment only: the large tier then misses late hand-overs)
     PROF_BEGIN_ON(12, st_rec);
     if (n_pairs && wave_on && small_cap)
-        hipLaunchKernelGGL(k_clip_pairs_rec, dim3(n_wg_rec), dim3(SURTR_WG), 0, st_rec, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+        hipLaunchKernelGGL(k_clip_pairs_rec, dim3(n_wg_rec), dim3(SURTR_S_THREADS), 0, st_rec, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool_rec, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list,
                            (const uint32_t*)(ctx->d_order + (size_t)32 * ctx->cap_order + (size_t)16 * n_pairs), ctx->d_order, walk0);
     PROF_END_ON(12, st_rec);
     PROF_BEGIN_ON(11, st2);
     if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st2);
-    if (n_pairs && wave_on)
+    uint32_t n_wg_main = n_wg;
+    if (const char* e = getenv("SURTR_MAIN_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= max_wg) n_wg_main = v; }
+    if (n_pairs && wave_on && split_on)
+        hipLaunchKernelGGL(k_clip_pairs_main, dim3(n_wg_main), dim3(SURTR_MAIN_THREADS), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, walk0);
+    else if (n_pairs && wave_on)
         hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u, walk0);
     if (n_pairs && wave_on) PROF_HIST_END(11, st2);
@@ -3368,6 +3506,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
     if (n_pairs && !wave_on) PROF_HIST_END(0, st2);
     PROF_END_ON(0, st2);
+    PROF_BEGIN_ON(13, st3);
+    if (n_pairs && wave_on && split_on)
+        hipLaunchKernelGGL(k_clip_pairs_catch, dim3(n_catch), dim3(SURTR_WG), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool, max_wg + ctx->n_wg_big, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, hcap, n_wg_main);
+    PROF_END_ON(13, st3);
     PROF_BEGIN_ON(9, st3);
     if (n_pairs && ctx->half_on)
         hipLaunchKernelGGL(k_clip_pairs_half, dim3(n_wg_half), dim3(SURTR_WGS), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,

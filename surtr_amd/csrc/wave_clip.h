@@ -121,18 +121,19 @@ __device__ __forceinline__ WcRec wc_rec(const unsigned char* B, uint32_t byte_of
 }
 // a 16-byte record at unit `unit` (park: none; loader / global copies use WcW4 directly)
 
-template <uint32_t NR, uint32_t NL = SURTR_WNL>
+template <uint32_t NR, uint32_t NL = SURTR_WNL, uint32_t NW = SURTR_NWAVE, bool GSTAGE = (NR < SURTR_WR)>
 struct alignas(16) WcLdsT
 {
     static constexpr uint32_t kNR = NR, kNL = NL;
+    static constexpr bool kGStage = GSTAGE;      // a plane whose stage does not fit works on the records in global memory (else: WC_BAIL)      // (NW: waves of the largest group a kernel with this LDS is launched with)
     alignas(16) unsigned char U[16u * NR];    // cut-point records from the bottom; the plane's stage and lists from the top
     float4 planes[WC_MAXF];
     uint16_t nlist[2][NL];             // alive cut points (ids) in creation order; the planes alternate between the two
     uint16_t freel[NL];                // record units of cut points that are gone
     uint32_t hist[WC_MAXF + 1], zhist[WC_MAXF + 1];
     uint32_t bst[WC_MAXF + 2];                // first id of bucket k (bucket F: never clipped); bst[F + 1] = n
-    uint32_t wcnt[SURTR_NWAVE][WC_MAXF + 2];  // loader: originals per (wave, bucket)
-    uint32_t wsum[2][2 * SURTR_NWAVE];        // ordered scans: totals per wave (two sets, alternating)
+    uint32_t wcnt[NW][WC_MAXF + 2];           // loader: originals per (wave, bucket)
+    uint32_t wsum[2][2 * NW];                 // ordered scans: totals per wave (two sets, alternating)
     uint32_t bsum[2][2u * (4096u / SURTR_LANES)];   // the item scan: totals per 64-item block (two sets, alternating)
     uint32_t fl[3][2];                        // group-wide flags, three sets in rotation (see wc_any)
     uint32_t zm[2];                           // planes some cut point lies in
@@ -531,8 +532,8 @@ __device__ __attribute__((always_inline)) inline int wc_planes(LT& W, const uint
         // works on the records where they are, in global memory (this XCD's L2: the item scan has just fetched them): its walk
         // steps through originals pay an L2 round trip instead of an LDS one, and the pair keeps its place in a kernel with a
         // smaller LDS area instead of being handed on.
-        // (only the kernels with less LDS than the regular one do this: there the alternative is to hand the pair on)
-        const bool gstage = LT::kNR < SURTR_WR && nCo != 0u && 4u * rtop + 8u * nCo + NI + (NI + 1u) / 2u + 7u * NI + 3u * nl + 128u > ltop;
+        // (only the kernels without the general clipper inside do this: there the alternative is to hand the pair on)
+        const bool gstage = LT::kGStage && nCo != 0u && 4u * rtop + 8u * nCo + NI + (NI + 1u) / 2u + 7u * NI + 3u * nl + 128u > ltop;
         if (4u * rtop + (gstage ? 0u : 8u * nCo) + NI + (NI + 1u) / 2u + 64u > ltop) WC_RET(4);
         WCOUNT(26, gstage ? 1 : 0);
         // stage: this plane's originals in LDS (their records are final: every patch of an earlier plane is in)

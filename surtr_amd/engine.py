@@ -162,7 +162,7 @@ class Engine:
     def kernel_times(self):
         ms = (ctypes.c_float * 16)()
         self._ck(lib().surtr_kernel_times(self._h, ms))
-        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry", "clip_pairs_wave", "clip_pairs_rec")
+        names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry", "clip_pairs_wave", "clip_pairs_rec", "clip_pairs_catch")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
     def kernel_history(self):

@@ -44,21 +44,22 @@ GatheredFragments AllGatherFragments(FractureEngine& engine, ncclComm_t comm, in
     if (rc) throw Error(rc, "surtr_get_stream");
     hipStream_t estream = (hipStream_t)es;
     DevBuf d_blob(stride), d_all(stride * (size_t)world);
-    hip_ck(hipMemsetAsync(d_blob.p, 0, stride, estream), "hipMemsetAsync");
+    // From here to the collective nothing throws: every rank enters the all-gather whatever happened to it, and errors are raised
+    // after it.  Without an event the pack is ordered before the collective by a synchronisation of the engine's stream.
+    const hipError_t e0 = hipMemsetAsync(d_blob.p, 0, stride, estream);
     rc = surtr_event_pack_dev(engine.Raw(), d_blob.p, stride);
     hipEvent_t packed = nullptr;
-    hip_ck(hipEventCreateWithFlags(&packed, hipEventDisableTiming), "hipEventCreate");
-    hipError_t e1 = hipEventRecord(packed, estream);
-    hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, packed, 0) : e1;
-    // (the collective is entered whatever happened above, so that no rank is left alone in it; errors are raised after it)
+    hipError_t e1 = hipEventCreateWithFlags(&packed, hipEventDisableTiming);
+    if (e1 == hipSuccess) e1 = hipEventRecord(packed, estream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(stream, packed, 0) : hipStreamSynchronize(estream);
     ncclResult_t nr = ncclAllGather(d_blob.p, d_all.p, stride, ncclUint8, comm, stream);
     GatheredFragments out;
     out.stride = stride; out.host.resize(stride * (size_t)world); out.counts.resize(world);
     hipError_t e3 = hipMemcpyAsync(out.host.data(), d_all.p, out.host.size(), hipMemcpyDeviceToHost, stream);
     hipError_t e4 = hipStreamSynchronize(stream);
-    (void)hipEventDestroy(packed);
+    if (packed) (void)hipEventDestroy(packed);
     if (rc) throw Error(rc, "surtr_event_pack_dev");
-    hip_ck(e1, "hipEventRecord"); hip_ck(e2, "hipStreamWaitEvent"); nccl_ck(nr, "ncclAllGather(blobs)"); hip_ck(e3, "hipMemcpyAsync"); hip_ck(e4, "hipStreamSynchronize");
+    hip_ck(e0, "hipMemsetAsync"); hip_ck(e1, "hipEventCreate / hipEventRecord"); hip_ck(e2, "hipStreamWaitEvent"); nccl_ck(nr, "ncclAllGather(blobs)"); hip_ck(e3, "hipMemcpyAsync"); hip_ck(e4, "hipStreamSynchronize");
     for (int r = 0; r < world; ++r)
     {
         rc = surtr_blob_unpack_host(out.host.data() + (size_t)r * stride, sizes[r], &out.counts[r], nullptr);

@@ -19,6 +19,7 @@
 // one vertex per "64-block" and per sphere group here: the LDS tables of k_prep_pairs (static arrays in this build) are sized so
 // that the test meshes take the same paths as 50 000-vertex pieces do on the device
 #define SURTR_PREP_NB 65536u
+#define SURTR_MAIN_THREADS 1u      // (one thread per workgroup in this build)
 #define SURTR_PS_NB 57344u
 #define SURTR_SMALL_LV 64
 #define SURTR_SMALL_LH 512
@@ -61,6 +62,8 @@ static inline bool __all(bool p) { return p; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __threadfence() {}
 static inline int __builtin_amdgcn_readlane(int v, int) { return v; }
 static inline int __builtin_amdgcn_update_dpp(int old, int, int, int, int, bool) { return old; }      // lane 0 never has a source lane
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
