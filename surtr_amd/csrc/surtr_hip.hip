@@ -753,6 +753,9 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifndef SURTR_PREP_WAVES
 #define SURTR_PREP_WAVES 7       // workgroups per CU = waves per SIMD: the register budget is set for that (<= 72 VGPRs)
 #endif
+// OLD_SELECT = false: every piece of the event takes the sorted selection (the host checks: up to 65 534 vertices each) -- round 3's
+// selection is then not compiled into the kernel (28 spilled registers -> 2)
+template <bool OLD_SELECT = true>
 __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Shared& sh, unsigned long long* lmask, uint2* lblk, uint32_t rec_on,
                                                          const Pieces& P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
@@ -844,12 +847,13 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             const SortedRings sr{P.mrow_s + m0, P.miperm + m0, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
             prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, fcb, needy, und, klist, walks, n, hsum);
         }
-        else prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
+        else if constexpr (OLD_SELECT) prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
         __syncthreads();
         STAMP(71);
         uint32_t fmt = IMG_NARROW, off16 = 0;
-        if (n == 0) fmt = IMG_EMPTY;
+        if (!OLD_SELECT && !sorted_sel) fmt = IMG_NONE;      // (cannot happen: the host launches this variant only when every piece qualifies)
+        else if (n == 0) fmt = IMG_EMPTY;
         else if (toolong || n > 2u * capV || hsum > 2u * SURTR_LH || n >= InLds::SENT) fmt = IMG_WIDE;
         // room for the cut points behind the positions, for the topology of the kernel that will take the pair
         const bool to_half = half_on && fits_half(n, hsum, capVs);
@@ -903,7 +907,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
             __syncthreads();
             // (also counts sh.nzero, collects sh.cutmask)
             if (sorted_sel) prepass_emit_klist(min, F, sh, T, bmask, bblk, klist, orig, (uint2*)und, n, hsum, maxb_rec);
-            else prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);
+            else if constexpr (OLD_SELECT) prepass_emit(min, F, sh, T, bmask, bblk, orig, n, hsum);
             STAMP(74);
             prepass_finish_hist(F, sh);
             uint32_t* hs = (uint32_t*)(img + lay.hist); uint32_t* zs = (uint32_t*)(img + lay.zhist); uint32_t* nz = (uint32_t*)(img + lay.nzero);
@@ -980,6 +984,20 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_
     __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
     unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
     prep_pairs_body(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap, heavy_need);
+}
+
+// the same for events whose every piece takes the sorted selection
+__global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(SURTR_PREP_WAVES, 8))) void k_prep_pairs_sorted(Pieces P, const float4* __restrict__ planes,
+                                                         const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
+                                                         uint32_t n_pairs, PrepPool pool, Arena A, ImgArena IA, uint32_t capV, uint32_t capVs,
+                                                         PairRec* __restrict__ pairs, const uint2* __restrict__ pair_list,
+                                                         uint32_t* __restrict__ order, const uint32_t* __restrict__ porder,
+                                                         uint32_t* __restrict__ horder, uint32_t half_on, uint32_t big_quota, uint32_t big_n, uint32_t rec_on, uint32_t small_cap, uint32_t heavy_need)
+{
+    __shared__ Shared sh;
+    __shared__ unsigned long long lbuf[2u * SURTR_PREP_NB];      // masks (first half) + per-block pairs (second half); the sorted selection's tables
+    unsigned long long* lmask = lbuf; uint2* lblk = (uint2*)(lbuf + SURTR_PREP_NB);
+    prep_pairs_body<false>(sh, lmask, lblk, rec_on, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, capV, capVs, pairs, pair_list, order, porder, horder, half_on, big_quota, big_n, small_cap, heavy_need);
 }
 
 // The same with four times the threads per pair, for events of so few pairs (a rank's block of a sharded event) that the
@@ -3452,6 +3470,10 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     const bool prep_wide = n_pairs != 0 && n_pairs <= wide_max && ctx->vmax >= 8192u;      // few pairs, large meshes
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
+                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
+    else if (n_pairs && !(rec_on & 2u) && ctx->vmax < 0xFFFFu && ctx->vmin >= SURTR_PREP_MINV && (ctx->vmax + SURTR_LANES - 1u) / SURTR_LANES <= SURTR_PREP_NB)
+        hipLaunchKernelGGL(k_prep_pairs_sorted, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
                            ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     else if (n_pairs)
