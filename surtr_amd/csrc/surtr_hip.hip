@@ -3409,7 +3409,9 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (const char* e = getenv("SURTR_WAVE_BIG_N")) big_n = (uint32_t)atoi(e);
     // the regular pairs through the record clipper (wave_clip.h) once the pairs queue up; k_prep_pairs then leaves their bands as
     // record images (rec_on)
-    bool wave_on = n_pairs > 3u * max_wg;
+    // (round 4, split arrangement, blocks of configs[3]: 2 048 pairs 1.83 against 2.23 ms for the event, 1 024 pairs 1.53 against 1.59,
+    //  512 pairs 1.40 against 1.32: from 3/2 of the workgroup count on)
+    bool wave_on = 2u * n_pairs > 3u * max_wg;
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
     uint32_t rec_on = wave_on ? 1u : 0u;
     if (const char* e = getenv("SURTR_REC")) rec_on = (wave_on && atoi(e) != 0) ? 1u : 0u;      // (tests / A-B: 0 = images + wc_load as in round 3)
