@@ -379,6 +379,9 @@ def main():
         clip_avg_ms = float(np.mean(clip_ms))
         # the Mesh clip runs in k_clip_pairs_wave (record clipper) or k_clip_pairs (general clipper), whichever the engine chose
         dom = "k_clip_pairs_wave" if np.mean(all_ms.get("clip_pairs_wave", [0.0])) > np.mean(all_ms.get("clip_pairs", [0.0])) else "k_clip_pairs"
+        dom_slot = dom[2:]
+        if dom == "k_clip_pairs_wave" and np.mean(all_ms.get("clip_pairs_catch", [0.0])) > 0.02:
+            dom = "k_clip_pairs_main"       # split arrangement (round 4): the record clipper alone; same timing slot as k_clip_pairs_wave
         achieved = ab["clip_kernel"] / (clip_avg_ms * 1e-3) / 1e9
         # HBM traffic of the kernel from the rocprofv3 PMC passes (scripts/pmc.sh), only while it describes THIS build:
         # profiles/traffic.json records the hash of the kernel sources it was measured on
@@ -396,7 +399,7 @@ def main():
                 traffic_note = "unreadable: %r" % (ex,)
         assert world == args.gpus, (world, args.gpus)
         prep_ms = float(np.mean(all_ms.get("prep_pairs", [float("nan")])))
-        dom_alone_ms = float(np.mean(all_ms.get(dom[2:], [float("nan")])))
+        dom_alone_ms = float(np.mean(all_ms.get(dom_slot, [float("nan")])))
         out = {
             "metric": "fragments/sec", "value": value, "unit": "fragments/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
@@ -425,7 +428,7 @@ def main():
                          "avg_launch_ms_alone": dom_alone_ms},
             # pre-pass + Mesh clip TOGETHER (one event alone on the GPU): the band of every pair is what the path moves between the
             # two, so their summed counter traffic against the same algorithmic bytes is the honest re-read factor
-            "roofline_front_half": {"kernels": ["k_prep_pairs", dom], "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "roofline_front_half": {"kernels": [rec.get("prep_kernel", "k_prep_pairs") if traffic_prep is not None else "k_prep_pairs", dom], "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                     "algorithmic_bytes": ab["clip_kernel"], "ms": prep_ms + dom_alone_ms,
                                     "achieved": ab["clip_kernel"] / ((prep_ms + dom_alone_ms) * 1e-3) / 1e9,
                                     "frac": ab["clip_kernel"] / ((prep_ms + dom_alone_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -23,8 +23,10 @@ for k in sorted(res):
         d = res[k]
         print("%-18s FETCH %10.0f KB  WRITE %10.0f KB  wave cycles %.3g  wait_any %.3g" % (k, d.get("FETCH_SIZE", 0), d.get("WRITE_SIZE", 0), d.get("SQ_WAVE_CYCLES", 0), d.get("SQ_WAIT_ANY", 0)))
 import bench
-dom = "k_clip_pairs_wave" if res.get("k_clip_pairs_wave", {}).get("SQ_WAVE_CYCLES", 0) > res.get("k_clip_pairs", {}).get("SQ_WAVE_CYCLES", 0) else "k_clip_pairs"
-clip, prep = res.get(dom, {}), res.get("k_prep_pairs", {})
+# the kernel that clips the Meshes: k_clip_pairs_main (split arrangement, round 4), k_clip_pairs_wave, or k_clip_pairs
+dom = max(("k_clip_pairs_main", "k_clip_pairs_wave", "k_clip_pairs"), key=lambda k: res.get(k, {}).get("SQ_WAVE_CYCLES", 0))
+prep_name = "k_prep_pairs_sorted" if "k_prep_pairs_sorted" in res else "k_prep_pairs"
+clip, prep = res.get(dom, {}), res.get(prep_name, {})
 # FETCH_SIZE correction: the guide's x2 holds for 16-B-per-lane streams; this kernel reads 16-B words of the images (x2) and
 # 2..12-B gathers.  With a calibration file the factor measured for its narrowest common access (dword gathers: bytes counted
 # per 64-B line touched) bounds the read side from above; without one the uncorrected figure is a lower bound.
@@ -38,7 +40,10 @@ rec = {"build_id": bench.kernel_build_id(), "kernel": dom,
        "k_clip_pairs_FETCH_SIZE_KB": clip.get("FETCH_SIZE"), "k_clip_pairs_WRITE_SIZE_KB": clip.get("WRITE_SIZE"),
        "fetch_correction": factor, "note": note,
        "k_clip_pairs_hbm_bytes_per_launch": int((clip.get("FETCH_SIZE", 0) * factor + clip.get("WRITE_SIZE", 0)) * 1024),
-       "k_prep_pairs_hbm_bytes_per_launch": int((prep.get("FETCH_SIZE", 0) * factor + prep.get("WRITE_SIZE", 0)) * 1024)}
+       "k_prep_pairs_hbm_bytes_per_launch": int((prep.get("FETCH_SIZE", 0) * factor + prep.get("WRITE_SIZE", 0)) * 1024),
+       "prep_kernel": prep_name,
+       # the kernels that run beside the dominant one on other streams (split arrangement): general clipper for irregular pairs / large bands
+       "beside": {k: int((res[k].get("FETCH_SIZE", 0) * factor + res[k].get("WRITE_SIZE", 0)) * 1024) for k in ("k_clip_pairs_catch", "k_clip_pairs_big") if k in res}}
 for k in ("TCC_HIT_sum", "TCC_MISS_sum", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS",
           "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
     if k in clip:
