@@ -445,12 +445,12 @@ __device__ __forceinline__ void prepass_keep_deg(uint2* bblk, Shared& sh, uint32
 
 // A2 of the pre-pass: the exact test, densely over the work list `needy` (v | fc << 24): a vertex is dropped iff every vertex
 // of every incident face has the same first clipping plane.  klist / kcount (optional, the sorted pre-pass of k_prep_pairs): the
-// kept vertices are appended as (vertex | (first clipping plane | 0x80 when the vertex lies in an earlier plane) << 24, sorted index
-// | ring length << 16);
+// kept vertices are appended as sorted index | (first clipping plane | 0x80 when the vertex lies in an earlier plane) << 16 | ring
+// length << 24;
 // sh.misc[5] = some kept vertex does.
 template <int NB>
 __device__ inline void prepass_exact(const SolidIn in, const uint32_t F, Shared& sh, unsigned long long* bmask, uint2* bblk,
-                                     const uint32_t* needy, const uint32_t nNeedy, uint2* klist = nullptr, uint32_t* kcount = nullptr, const uint32_t* iperm = nullptr)
+                                     const uint32_t* needy, const uint32_t nNeedy, uint32_t* klist = nullptr, uint32_t* kcount = nullptr, const uint32_t* iperm = nullptr)
 {
     const uint32_t l = lane_id(), w = wave_id();
     const uint32_t V = in.nv;
@@ -514,7 +514,7 @@ __device__ inline void prepass_exact(const SolidIn in, const uint32_t F, Shared&
                     const float px = in.pos[3 * v], py = in.pos[3 * v + 1], pz = in.pos[3 * v + 2];
                     uint32_t z = 0;
                     for (uint32_t k = 0; k < f; ++k) if (side_of(plane_dist(sh.planes[k], px, py, pz)) == 0) z = 0x80u;
-                    klist[atomicAdd(kcount, 1u)] = make_uint2(v | ((f | z) << 24), iperm[v] | ((deg < 255u ? deg : 255u) << 16));
+                    klist[atomicAdd(kcount, 1u)] = iperm[v] | ((f | z) << 16) | ((deg < 255u ? deg : 255u) << 24);
                     if (z) sh.misc[5] = 1u;
                 }
             }

@@ -74,6 +74,16 @@ __device__ __forceinline__ void ps_append(uint32_t* list, uint32_t* counter, boo
     if (on) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull))] = value;
 }
 
+__device__ __forceinline__ void ps_append16(uint16_t* list, uint32_t* counter, bool on, uint32_t value)
+{
+    const unsigned long long m = __ballot(on);
+    if (!m) return;
+    const uint32_t l = lane_id();
+    uint32_t base = 0;
+    if (l == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    base = lane_bcast(base, (uint32_t)__builtin_ctzll(m));
+    if (on) list[base + (uint32_t)__builtin_popcountll(m & ((1ull << l) - 1ull))] = (uint16_t)value;
+}
 __device__ __forceinline__ void ps_append2(uint2* list, uint32_t* counter, bool on, uint2 value)
 {
     const unsigned long long m = __ballot(on);
@@ -90,13 +100,15 @@ __device__ __forceinline__ void ps_append2(uint2* list, uint32_t* counter, bool 
 // not fit goes to vfc_g), then `ubw` words "set bits before this word" and `ubw` words of one bit per group ("undecided").
 // On return it holds what the emits read: bmask (one 64-bit word per 64 vertices, first half) and bblk (one pair per 64
 // vertices, second half; x: kept vertices before the block, y: their ring entries), built from the kept list.
-// vfc_g, needy, und, klist, walks: global scratch (V entries each at most; und: one per group); kst: global scratch, one byte per group.
+// vfc_g, needy, und, klist, walks: global scratch (V entries each at most; und: one per group; needy, und: 16-bit sorted indices /
+// groups -- what moves between the passes of this kernel is what its counter traffic is made of).
 // Requires in.nv < 65535, ceil(in.nv / SURTR_SB) <= 32 * ubw, in.nv <= 64 * NB, the sorted copy.
-// Leaves: klist[0 .. n) = (vertex | (fc | 0x80: in a plane before fc) << 24, sorted index | ring length << 16), in no order;
+// Leaves: klist[0 .. n) = sorted index | (fc | 0x80: in a plane before fc) << 16 | ring length (255: more) << 24, in no order
+// (the vertex is perm[sorted index]);
 // sh.hist / zhist raw (prepass_finish_hist); sh.misc[5] = a kept vertex lies in a plane before its fc; sh.deg7, sh.flagBad.
 template <uint32_t NB, uint32_t UBW>
 __device__ __attribute__((always_inline)) inline void prepass_select_sorted(const SolidIn in, const SortedRings sr, const uint32_t F, Shared& sh,
-                                                                            unsigned char* lbuf, uint8_t* vfc_g, uint8_t* kst, uint32_t* needy, uint32_t* und, uint2* klist, uint32_t* walks,
+                                                                            unsigned char* lbuf, uint8_t* vfc_g, uint16_t* needy, uint16_t* und, uint32_t* klist, uint32_t* walks,
                                                                             uint32_t& n_out, uint32_t& hsum_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
@@ -165,7 +177,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         uint32_t ks = 0;
         const uint32_t f = ps_sphere_fc(sh, F, in.bsph[sb], e2 >> 16, ks);
         if (f != 0xFFu) atomicAdd(&sh.hist[f], verts_in(sb, sb + 1u));
-        else { atomicOr(&ub[sb >> 5], 1u << (sb & 31u)); kst[sb] = (uint8_t)ks; }
+        else atomicOr(&ub[sb >> 5], 1u << (sb & 31u));
     }
     __syncthreads();
     // the undecided groups in ascending (Morton) order, from the bits: und[rank] = group, pre[q] = set bits before word q.  The
@@ -185,7 +197,7 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
             {
                 uint32_t at = carry + woff + inc - c;
                 pre[q] = at;
-                for (uint32_t m = ub[q]; m; m &= m - 1u) { const uint32_t g = 32u * q + (uint32_t)__builtin_ctz(m); und[at++] = g | ((uint32_t)kst[g] << 24); }
+                for (uint32_t m = ub[q]; m; m &= m - 1u) und[at++] = (uint16_t)(32u * q + (uint32_t)__builtin_ctz(m));
             }
             carry += tot;
             __syncthreads();
@@ -208,20 +220,14 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     {
         const uint32_t sub = wb * GPW + l / SURTR_SB;
         const bool okg = sub < nUnd;
-        const uint32_t ue = okg ? und[sub] : 0xFF000000u;
-        const uint32_t i = (ue & 0xFFFFFFu) * SURTR_SB + (l % SURTR_SB);
+        const uint32_t i = (okg ? (uint32_t)und[sub] : 0u) * SURTR_SB + (l % SURTR_SB);
         const bool valid = okg && i < V;
         const float4 pr = in.posr_s[valid ? i : 0u];
         const float mag = fabsf(pr.x) + fabsf(pr.y) + fabsf(pr.z);
-        // the planes before the one the group's sphere test stopped at have the whole group, balls included, strictly on their
-        // kept side: they clip nothing here, hold no vertex, and leave the ball test as it is -- the loop starts at the earliest
-        // such plane of the wave-load's groups (neighbours in space: the list is in Morton order)
-        uint32_t kmin = 0xFFu;
-#pragma unroll
-        for (uint32_t q = 0; q < GPW; ++q) { const uint32_t kq = lane_bcast(ue >> 24, q * SURTR_SB); kmin = kq < kmin ? kq : kmin; }
+        // (starting the loop at the plane the group's sphere test stopped at was measured: +-0 -- the band lies ON the early planes)
         uint32_t f = PS_NEVER, z = 0u;
         bool done = !valid, clear = true;
-        for (uint32_t k = kmin; k < F; ++k)
+        for (uint32_t k = 0; k < F; ++k)
         {
             if (__all(done)) break;
             const float4 mk = sh.pmar[k];
@@ -239,14 +245,14 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         const bool drop = valid && !never && clear;          // (|s| > margin at every plane up to fc: in no plane either)
         const bool need = valid && !never && !clear;
         wave_hist_add(sh.hist, f, drop);
-        ps_append(needy, &sh.misc[3], need, i | ((f | z) << 24));
+        ps_append16(needy, &sh.misc[3], need, i);
         if (__ballot(never))
         {
             // never clipped: kept whatever its neighbours are
             const uint32_t v = never ? in.perm[i] : 0u;
             const uint32_t deg = never ? in.llen[v] : 0u;
             if (never && z) sh.misc[5] = 1u;
-            ps_append2(klist, &sh.misc[6], never, make_uint2(v | ((f | z) << 24), i | ((deg < 255u ? deg : 255u) << 16)));
+            ps_append(klist, &sh.misc[6], never, i | ((f | z) << 16) | ((deg < 255u ? deg : 255u) << 24));
         }
     }
     __syncthreads();
@@ -262,9 +268,17 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     {
         const uint32_t t = t0 + l;
         const bool valid = t < nNeedy;
-        const uint32_t e = valid ? needy[t] : 0u;
-        const uint32_t i = e & 0xFFFFFFu, byte = e >> 24, f = byte & 0x7Fu;
+        const uint32_t i = valid ? (uint32_t)needy[t] : 0u;
         const SRow row = sr.row_s[i];
+        // its own byte: at (rank of its group) * SB + place, like its neighbours' below
+        uint32_t byte;
+        {
+            const uint32_t g = i / SURTR_SB, word = ub[g >> 5], bit = g & 31u;
+            const uint32_t at = (pre[g >> 5] + (uint32_t)__builtin_popcount(word & ((1u << bit) - 1u))) * SURTR_SB + i % SURTR_SB;
+            byte = (valid && at < kCap) ? (uint32_t)vfc[valid ? at : 0u] : 0u;
+            if (valid && at >= kCap) byte = vfc_g[at];
+        }
+        const uint32_t f = byte & 0x7Fu;
         const uint32_t hd = row.w[0] & 0xFFFFu;
         const uint32_t deg = valid ? (hd & 7u) : 0u, notri = (hd >> 7) & 1u, big = (hd >> 6) & 1u;
         // the first clipping plane of every neighbour in an undecided group: its byte sits at (rank of the group) * SB + place
@@ -288,11 +302,11 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
         // all neighbours agree but the faces are larger than the 1-ring, or the ring is not in the row: the exact test with face walks
         const bool walk = valid && (big != 0u || (notri != 0u && !differ));
         const bool keep = valid && differ && !walk, drop = valid && !differ && !walk;
-        if (__ballot(keep | walk))
+        if (keep && (byte & 0x80u)) sh.misc[5] = 1u;
+        ps_append(klist, &sh.misc[6], keep, i | (byte << 16) | (deg << 24));
+        if (__ballot(walk))
         {
-            const uint32_t v = (keep | walk) ? in.perm[i] : 0u;
-            if (keep && (byte & 0x80u)) sh.misc[5] = 1u;
-            ps_append2(klist, &sh.misc[6], keep, make_uint2(v | (byte << 24), i | (deg << 16)));
+            const uint32_t v = walk ? in.perm[i] : 0u;
             ps_append(walks, &sh.misc[0], walk, v | (f << 24));
         }
         wave_hist_add(sh.hist, f, drop);
@@ -314,8 +328,8 @@ __device__ __attribute__((always_inline)) inline void prepass_select_sorted(cons
     __syncthreads();
     for (uint32_t t = tid; t < n; t += G)
     {
-        const uint2 ke = klist[t];
-        const uint32_t v = ke.x & 0xFFFFFFu, deg = ke.y >> 16;
+        const uint32_t ke = klist[t];
+        const uint32_t v = in.perm[ke & 0xFFFFu], deg = ke >> 24;
         atomicOr(&bmask[v >> SURTR_LSH], 1ull << (v & (SURTR_LANES - 1u)));
         uint32_t d = deg;
         if (deg >= 255u) d = in.llen[v];
@@ -344,7 +358,7 @@ __device__ __forceinline__ uint32_t ps_newid(const unsigned long long* bmask, co
 // without its sweep over every 64-vertex block of the piece and without its plane loop (the first clipping planes are in the list;
 // only a vertex that lies in a plane before its fc is evaluated again, for sh.nzero).  scan: global, ceil(n / 64) + 2 pairs.
 __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const SolidIn in, const uint32_t F, Shared& sh, Topo<InLds>& T, const unsigned long long* bmask,
-                                                                         const uint2* bblk, const uint2* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum, uint32_t& maxb_out)
+                                                                         const uint2* bblk, const uint32_t* klist, uint32_t* orig, uint2* scan, const uint32_t n, const uint32_t hsum, uint32_t& maxb_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
     STAMP_DECL;
@@ -354,16 +368,16 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_klist(const S
     __syncthreads();
     for (uint32_t t = tid; t < n; t += G)
     {
-        const uint2 ke = klist[t];
-        const uint32_t v = ke.x & 0xFFFFFFu, byte = ke.x >> 24, f = byte & 0x7Fu;
+        const uint32_t ke = klist[t], si = ke & 0xFFFFu;
+        const uint32_t v = in.perm[si], byte = (ke >> 16) & 0xFFu, f = byte & 0x7Fu;
         const uint32_t id = ps_newid(bmask, bblk, v, 0u);
-        orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
-        T.llen[id] = (uint8_t)((ke.y >> 16) < 255u ? (ke.y >> 16) : in.llen[v]);
+        orig[id] = v | (si << 16);          // (vertex, sorted index: both below 65 535 here)
+        T.llen[id] = (uint8_t)((ke >> 24) < 255u ? (ke >> 24) : in.llen[v]);
         T.fc[id] = (uint8_t)(f == PS_NEVER ? SURTR_NEVER : f);
         if (f != PS_NEVER) { atomicOr(&sh.cutmask[f >> 5], 1u << (f & 31u)); if (f < F) atomicAdd(&sh.pw[f], 1u); }
         if (byte & 0x80u)
         {
-            const float4 pr = in.posr_s[ke.y & 0xFFFFu];
+            const float4 pr = in.posr_s[si];
             const float px = pr.x, py = pr.y, pz = pr.z;
             for (uint32_t k = 0; k < F; ++k)
             {
@@ -430,7 +444,7 @@ __host__ __device__ static inline RecLayout rec_layout(uint32_t F, uint32_t n)
 // ncut_out: planes that are the first clipping plane of some band vertex (the cost estimate of the clip); maxb_out: the largest
 // number of band vertices one plane clips (what the record clipper's LDS need at its worst plane follows).
 __device__ __attribute__((always_inline)) inline void prepass_emit_records(const SolidIn in, const uint32_t F, Shared& sh, const unsigned long long* bmask, const uint2* bblk,
-                                                                           const uint2* klist, uint32_t* orig, uint8_t* fcb, uint16_t* sid16, uint32_t* cnt,
+                                                                           const uint32_t* klist, uint32_t* orig, uint8_t* fcb, uint16_t* sid16, uint32_t* cnt,
                                                                            char* img, const uint32_t n, uint32_t& ncut_out, uint32_t& maxb_out)
 {
     const uint32_t tid = threadIdx.x, l = lane_id(), w = wave_id(), G = group_size(), nw = group_waves();
@@ -439,11 +453,11 @@ __device__ __attribute__((always_inline)) inline void prepass_emit_records(const
     // ---- band order = ascending vertex index: orig[id], first clipping plane of id ----
     for (uint32_t t = tid; t < n; t += G)
     {
-        const uint2 ke = klist[t];
-        const uint32_t v = ke.x & 0xFFFFFFu;
+        const uint32_t ke = klist[t], si = ke & 0xFFFFu;
+        const uint32_t v = in.perm[si];
         const uint32_t id = ps_newid(bmask, bblk, v, 0u);
-        orig[id] = v | (ke.y << 16);          // (vertex, sorted index: both below 65 535 here)
-        fcb[id] = (uint8_t)((ke.x >> 24) & 0x7Fu);
+        orig[id] = v | (si << 16);          // (vertex, sorted index: both below 65 535 here)
+        fcb[id] = (uint8_t)((ke >> 16) & 0x7Fu);
     }
     // sort waves: at most four take part in the ranking (contiguous ranges of 64-vertex blocks of the band)
     const uint32_t nsw = nw < 4u ? nw : 4u;

@@ -56,7 +56,7 @@ static size_t prep_bytes_per_wg(uint32_t VMAX)
     auto r = [](size_t b) { return (b + 255) & ~(size_t)255; };
     return 2 * r((size_t)VMAX * 4) + r((size_t)(VMAX / SURTR_SB + 2) * 4) + 2 * r((size_t)(VMAX / SURTR_LANES + 2) * 8) +
            2 * r((size_t)VMAX + 64) +     // + first clipping planes of the undecided groups' vertices / by band index (prep_sorted.h)
-           r((size_t)VMAX * 8) + r((size_t)VMAX * 4) +      // + kept list (pairs), face-walk list
+           2 * r((size_t)VMAX * 4) +      // + kept list, face-walk list
            r((size_t)VMAX * 2 + 64);      // + sorted id by band index (record emit)
 }
 

@@ -780,7 +780,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
     uint2* gblk = (uint2*)take((size_t)(pool.VMAX / SURTR_LANES + 2) * 8);
     uint8_t* vfc = (uint8_t*)take((size_t)pool.VMAX + 64);
     uint8_t* fcb = (uint8_t*)take((size_t)pool.VMAX + 64);
-    uint2* klist = (uint2*)take((size_t)pool.VMAX * 8);
+    uint32_t* klist = (uint32_t*)take((size_t)pool.VMAX * 4);
     uint32_t* walks = (uint32_t*)take((size_t)pool.VMAX * 4);
     uint16_t* sid16 = (uint16_t*)take((size_t)pool.VMAX * 2 + 64);
 #ifdef SURTR_STAMP
@@ -845,7 +845,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         if (sorted_sel)
         {
             const SortedRings sr{P.mrow_s + m0, P.miperm + m0, P.mbsph2 + P.mbo2[piece], P.mbsph3 + P.mbo3[piece]};
-            prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, fcb, needy, und, klist, walks, n, hsum);
+            prepass_select_sorted<SURTR_PREP_NB, kUbWords>(min, sr, F, sh, (unsigned char*)lmask, vfc, (uint16_t*)needy, (uint16_t*)und, klist, walks, n, hsum);
         }
         else if constexpr (OLD_SELECT) prepass_select<SURTR_PREP_G, SURTR_PREP_NBATCH>(min, F, sh, bmask, bblk, needy, und, n, hsum);
         const bool toolong = sh.flagBad != 0;
