@@ -3411,7 +3411,12 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // record images (rec_on)
     // (round 4, split arrangement, blocks of configs[3]: 2 048 pairs 1.83 against 2.23 ms for the event, 1 024 pairs 1.53 against 1.59,
     //  512 pairs 1.40 against 1.32: from 3/2 of the workgroup count on)
-    bool wave_on = 2u * n_pairs > 3u * max_wg;
+    // ... and for events of any size over pieces whose bands come as record images as a rule (every piece pre-passed by k_prep_pairs
+    // and small enough that a band seldom passes SURTR_REC_MAXN vertices): one pair on the record clipper alone takes 0.18 ms where
+    // the general clipper takes 0.26 (configs[1]: 0.73 -> 0.72 ms per event, configs[2]: 1.06 -> 1.00)
+    // (SURTR_HALF=1 -- tests that want the half-size general kernel -- keeps such events on it)
+    const bool half_forced = getenv("SURTR_HALF") != nullptr && atoi(getenv("SURTR_HALF")) != 0;
+    bool wave_on = 2u * n_pairs > 3u * max_wg || (!half_forced && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= 4u * SURTR_REC_MAXN);
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
     uint32_t rec_on = wave_on ? 1u : 0u;
     if (const char* e = getenv("SURTR_REC")) rec_on = (wave_on && atoi(e) != 0) ? 1u : 0u;      // (tests / A-B: 0 = images + wc_load as in round 3)
@@ -3435,6 +3440,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // one-kernel arrangement has on every workgroup
     bool split_on = wave_on && !small_cap && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= ctx->prep.VMAX;
     if (const char* e = getenv("SURTR_SPLIT")) split_on = split_on && atoi(e) != 0;
+    // (the split arrangement takes the light pairs too: the half-size general kernel stays out of it)
+    const bool use_half = ctx->half_on && (!split_on || half_forced);
     // (measured on configs[3]: 16 .. 32 workgroups end with the main kernel -- 35 pairs with a vertex in a plane + a hand-over or two;
     //  64 and more take LDS from it: 2.50 / 2.50 / 2.56 ms per event with 16 / 32 / 64)
     uint32_t n_catch = std::min(std::min(ctx->n_wg_catch, 32u), std::max(n_pairs, 1u));
@@ -3473,15 +3480,15 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, use_half ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     else if (n_pairs && !(rec_on & 2u) && ctx->vmax < 0xFFFFu && ctx->vmin >= SURTR_PREP_MINV && (ctx->vmax + SURTR_LANES - 1u) / SURTR_LANES <= SURTR_PREP_NB)
         hipLaunchKernelGGL(k_prep_pairs_sorted, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, use_half ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     else if (n_pairs)
         hipLaunchKernelGGL(k_prep_pairs, dim3(n_wg_prep), dim3(SURTR_WG), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
-                           ctx->d_order + (size_t)32 * ctx->cap_order, ctx->half_on ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
+                           ctx->d_order + (size_t)32 * ctx->cap_order, use_half ? 1u : 0u, big_quota, big_n, rec_on, small_cap, heavy_need);
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
@@ -3536,7 +3543,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->pool, max_wg + ctx->n_wg_big, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, hcap, n_wg_main);
     PROF_END_ON(13, st3);
     PROF_BEGIN_ON(9, st3);
-    if (n_pairs && ctx->half_on)
+    if (n_pairs && use_half)
         hipLaunchKernelGGL(k_clip_pairs_half, dim3(n_wg_half), dim3(SURTR_WGS), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool_half, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)32 * ctx->cap_order);
     PROF_END_ON(9, st3);
@@ -3545,7 +3552,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
     // (it reuses the scratch slots of the first launch)
     PROF_BEGIN_ON(10, st2);
-    if (n_pairs && ctx->half_on)
+    if (n_pairs && use_half)
         hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
     PROF_END_ON(10, st2);
