@@ -17,17 +17,22 @@
 #pragma once
 #include "clip_core.h"
 
-#define SC_V 256u            // vertices of the solid at any time
-#define SC_H 1024u           // ring entries
+#define SC_V 192u            // vertices of the solid at any time
+#define SC_H 640u            // ring entries
 #define SC_FALLBACK 101      // internal: not regular / does not fit -> general clipper
 
 namespace surtr {
 
+// The solid in LDS.  A ring entry carries, beside the neighbour's id, the slot of the reverse entry in the neighbour's ring (its
+// "twin"), so that a face walk and the renumbering of the compaction never search a ring: entry = id | twin << 16.  The twins
+// are found once, when the solid is loaded; a regular plane keeps them up to date for free -- the ring of a kept vertex keeps
+// its length and order (:350-354 patch entries in place), and a new vertex [pred, succ, kept end] is entry 1 of its predecessor,
+// entry 0 of its successor, and takes the place of its clipped end in the kept end's ring.
 struct ScSolid
 {
     float pos[3 * SC_V];
-    uint16_t loff[SC_V]; uint8_t llen[SC_V];
-    uint16_t ring[SC_H];
+    uint32_t vw[SC_V];                    // ring offset | ring length << 16
+    uint32_t re[SC_H];                    // neighbour | twin slot << 16
 };
 
 struct ScLds
@@ -35,21 +40,14 @@ struct ScLds
     ScSolid buf[2];
     int8_t c[SC_V];                       // comp of the plane in progress
     uint16_t km[SC_V];                    // clipped vertex: bit j = ring slot j holds a kept neighbour
-    uint16_t base[SC_V];                  // clipped vertex: number of its first new vertex
-    uint16_t newidx[SC_V];                // kept vertex: its index after the compaction
+    uint16_t mp[SC_V];                    // kept vertex: its index after the compaction; clipped: 0x8000 | number of its first new vertex
     uint16_t noff[SC_V];                  // kept vertex: its ring offset after the compaction
     uint16_t succ[SC_V], pred[SC_V];      // per new vertex
     uint32_t nv[2], flag;
+#ifdef SURTR_STAMP
+    unsigned long long tph[8];            // lane 0's cycles: load, classify, numbering, relink, check, compaction; cutting planes
+#endif
 };
-
-// slot of `who` in the ring of v (its length when absent)
-__device__ __forceinline__ uint32_t sc_slot(const ScSolid& S, uint32_t v, uint32_t who)
-{
-    const uint16_t* r = S.ring + S.loff[v]; const uint32_t n = S.llen[v];
-    uint32_t q = 0;
-    while (q < n && (uint32_t)r[q] != who) ++q;
-    return q;
-}
 
 // Clips `in` by sh.planes[0..F).  0: done, the result is L.buf[*which] with L.nv[*which] vertices (0 = empty);
 // SC_FALLBACK: use the general clipper.  One wave; every lane must call it.
@@ -57,6 +55,13 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
 {
     const uint32_t lane = lane_id();
     const uint32_t V = in.nv;
+#ifdef SURTR_STAMP
+    unsigned long long sc_t0 = __builtin_readcyclecounter();
+    if (lane == 0) for (int q = 0; q < 8; ++q) L.tph[q] = 0;
+#define SC_STAMP(i) do { if (lane == 0) { const unsigned long long t1 = __builtin_readcyclecounter(); L.tph[i] += t1 - sc_t0; sc_t0 = t1; } } while (0)
+#else
+#define SC_STAMP(i) do { } while (0)
+#endif
     if (V == 0 || V > SC_V) return SC_FALLBACK;
     const uint32_t hbase = in.loff[0], H = in.loff[V - 1u] + in.llen[V - 1u] - hbase;
     if (H > SC_H) return SC_FALLBACK;
@@ -67,11 +72,13 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         S.pos[3 * v] = in.pos[3 * v]; S.pos[3 * v + 1] = in.pos[3 * v + 1]; S.pos[3 * v + 2] = in.pos[3 * v + 2];
         const uint32_t lo = in.loff[v] - hbase, deg = in.llen[v];
         if (deg > 15u || deg < 3u) odd = true;
-        S.loff[v] = (uint16_t)lo; S.llen[v] = (uint8_t)(deg > 15u ? 15u : deg);
+        const uint32_t dl = deg > 15u ? 15u : deg;
+        S.vw[v] = lo | (dl << 16);
         const int32_t* r = in.nbr + in.loff[v];
-        for (uint32_t j = 0; j < deg && lo + j < SC_H; ++j)
+        for (uint32_t j = 0; j < dl && lo + j < SC_H; ++j)
         {
-            S.ring[lo + j] = (uint16_t)r[j];
+            if ((uint32_t)r[j] >= V) odd = true;
+            S.re[lo + j] = (uint32_t)r[j] & 0xFFFFu;
             // A ring that lists a vertex twice (slivers) makes the reference's first-occurrence patches and walks order
             // dependent: the general clipper reproduces that, this one does not try.  Checked once, here: a regular plane
             // cannot create such a ring in a kept vertex (its clipped neighbours become the distinct new vertices of distinct
@@ -81,6 +88,24 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
     }
     if (__ballot(odd) != 0ull) return SC_FALLBACK;
     __syncthreads();
+    // the twins: slot of v in the ring of every neighbour (a neighbour that does not list v back: not regular)
+    for (uint32_t v = lane; v < V; v += SURTR_LANES)
+    {
+        ScSolid& S = L.buf[0];
+        const uint32_t w = S.vw[v], lo = w & 0xFFFFu, deg = w >> 16;
+        for (uint32_t j = 0; j < deg; ++j)
+        {
+            const uint32_t e = S.re[lo + j] & 0xFFFFu;
+            const uint32_t we = S.vw[e], elo = we & 0xFFFFu, edeg = we >> 16;
+            uint32_t q = 0;
+            while (q < edeg && (S.re[elo + q] & 0xFFFFu) != v) ++q;
+            if (q >= edeg) odd = true;
+            S.re[lo + j] = e | (q << 16);      // (only this lane writes the high half of its own entries; the others read the low half)
+        }
+    }
+    if (__ballot(odd) != 0ull) return SC_FALLBACK;
+    __syncthreads();
+    SC_STAMP(0);
     uint32_t cur = 0, nv = V;
     for (uint32_t k = 0; k < F && nv != 0u; ++k)
     {
@@ -98,6 +123,7 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         if (__ballot(cut) == 0ull) continue;                         // "above": nothing to do (the solid has >= 4 vertices)
         if (__ballot(keep) == 0ull) { nv = 0; break; }               // "below": everything goes (:322-327)
         __syncthreads();
+        SC_STAMP(1);
         // ---- new vertices in (clipped vertex, slot) order; kept vertices' new indices and ring offsets ----
         uint32_t carryM = 0, carryK = 0, carryH = 0;
         for (uint32_t v0 = 0; v0 < nv; v0 += SURTR_LANES)
@@ -106,11 +132,11 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             uint32_t mask = 0, isKept = 0, deg = 0;
             if (v < nv)
             {
-                deg = S.llen[v];
-                const uint16_t* r = S.ring + S.loff[v];
+                const uint32_t w = S.vw[v], lo = w & 0xFFFFu;
+                deg = w >> 16;
                 if (L.c[v] > 0) isKept = 1u;
                 else
-                    for (uint32_t j = 0; j < deg; ++j) if (L.c[r[j]] > 0) mask |= 1u << j;
+                    for (uint32_t j = 0; j < deg; ++j) if (L.c[S.re[lo + j] & 0xFFFFu] > 0) mask |= 1u << j;
             }
             const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
             // one scan for the three running sums: new vertices | kept vertices << 16, kept ring entries
@@ -118,8 +144,7 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             if (v < nv)
             {
                 L.km[v] = (uint16_t)mask;
-                L.base[v] = (uint16_t)(carryM + (inc.x & 0xFFFFu) - cnt);
-                L.newidx[v] = (uint16_t)(carryK + (inc.x >> 16) - isKept);
+                L.mp[v] = isKept ? (uint16_t)(carryK + (inc.x >> 16) - 1u) : (uint16_t)(0x8000u | (carryM + (inc.x & 0xFFFFu) - cnt));
                 L.noff[v] = (uint16_t)(carryH + inc.y - (isKept ? deg : 0u));
             }
             const uint32_t tx = lane_bcast(inc.x, SURTR_LANES - 1u), ty = lane_bcast(inc.y, SURTR_LANES - 1u);
@@ -130,25 +155,27 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         if (nKeep + M < 4u) { nv = 0; break; }                        // (:497-499)
         for (uint32_t t = lane; t < M; t += SURTR_LANES) L.pred[t] = 0xFFFFu;
         __syncthreads();
+        SC_STAMP(2);
         // ---- relink: successor of every new vertex along the face through its clipped end ----
         bool bad = false;
         for (uint32_t v = lane; v < nv; v += SURTR_LANES)
         {
             uint32_t mask = L.c[v] < 0 ? L.km[v] : 0u;
-            uint32_t t = L.base[v];
+            if (!mask) continue;
+            uint32_t t = L.mp[v] & 0x7FFFu;
+            const uint32_t wv = S.vw[v];
             for (; mask; mask &= mask - 1u, ++t)
             {
                 // new vertex X on the edge (v, slot j): FaceLoop from X through v takes the entry before slot j, and so on
-                uint32_t cv = v, slot = (uint32_t)__builtin_ctz(mask), steps = 0, end = 0xFFFFu;
+                uint32_t cv = v, w = wv, slot = (uint32_t)__builtin_ctz(mask), steps = 0, end = 0xFFFFu;
                 while (steps++ <= nv)
                 {
-                    const uint32_t len = S.llen[cv];
+                    const uint32_t len = w >> 16;
                     const uint32_t p = slot == 0u ? len - 1u : slot - 1u;
-                    const uint32_t e = S.ring[S.loff[cv] + p];
-                    if (L.c[e] > 0) { end = L.base[cv] + (uint32_t)__builtin_popcount(L.km[cv] & ((1u << p) - 1u)); break; }
-                    const uint32_t q = sc_slot(S, e, cv);             // the walk arrives at clipped e from cv
-                    if (q >= S.llen[e]) break;
-                    cv = e; slot = q;
+                    const uint32_t rw = S.re[(w & 0xFFFFu) + p];
+                    const uint32_t e = rw & 0xFFFFu;
+                    if (L.c[e] > 0) { end = (L.mp[cv] & 0x7FFFu) + (uint32_t)__builtin_popcount(L.km[cv] & ((1u << p) - 1u)); break; }
+                    cv = e; slot = rw >> 16; w = S.vw[e];              // the walk arrives at clipped e from cv: the twin is the slot
                 }
                 if (end == 0xFFFFu || end == t) { bad = true; continue; }
                 L.succ[t] = (uint16_t)end;
@@ -157,41 +184,38 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         }
         if (__ballot(bad) != 0ull) return SC_FALLBACK;
         __syncthreads();
+        SC_STAMP(3);
         // (pred == succ: a cap of two vertices, i.e. a new ring that lists a vertex twice)
         for (uint32_t t = lane; t < M; t += SURTR_LANES) if (L.pred[t] == 0xFFFFu || L.pred[L.succ[t]] != t || L.pred[t] == L.succ[t]) bad = true;
         if (__ballot(bad) != 0ull) return SC_FALLBACK;
+        SC_STAMP(4);
         // ---- the solid after this plane, compacted (:464-495): kept vertices in order, then the new ones ----
         for (uint32_t v = lane; v < nv; v += SURTR_LANES)
         {
-            const uint16_t* r = S.ring + S.loff[v];
-            const uint32_t deg = S.llen[v];
+            const uint32_t w = S.vw[v], lo0 = w & 0xFFFFu, deg = w >> 16;
             if (L.c[v] > 0)
             {
-                const uint32_t id = L.newidx[v], lo = L.noff[v];
+                const uint32_t id = L.mp[v], lo = L.noff[v];
                 N.pos[3 * id] = S.pos[3 * v]; N.pos[3 * id + 1] = S.pos[3 * v + 1]; N.pos[3 * id + 2] = S.pos[3 * v + 2];
-                N.loff[id] = (uint16_t)lo; N.llen[id] = (uint8_t)deg;
+                N.vw[id] = lo | (deg << 16);
                 for (uint32_t j = 0; j < deg; ++j)
                 {
-                    const uint32_t e = r[j];
-                    uint32_t to;
-                    if (L.c[e] > 0) to = L.newidx[e];
-                    else
-                    {
-                        // the link to a clipped neighbour now holds the new vertex on that edge (:350-354)
-                        const uint32_t q = sc_slot(S, e, v);
-                        to = nKeep + L.base[e] + (uint32_t)__builtin_popcount(L.km[e] & ((1u << q) - 1u));
-                    }
-                    N.ring[lo + j] = (uint16_t)to;
+                    const uint32_t rw = S.re[lo0 + j], e = rw & 0xFFFFu, q = rw >> 16;
+                    const uint32_t m = L.mp[e], kme = L.km[e];
+                    // a kept neighbour under its new number, same twin; the link to a clipped neighbour now holds the new vertex on
+                    // that edge (:350-354), whose third entry this vertex is
+                    N.re[lo + j] = (m & 0x8000u) ? (nKeep + (m & 0x7FFFu) + (uint32_t)__builtin_popcount(kme & ((1u << q) - 1u))) | (2u << 16)
+                                                 : m | (q << 16);
                 }
             }
             else
             {
                 const float ax = S.pos[3 * v], ay = S.pos[3 * v + 1], az = S.pos[3 * v + 2];
                 const float sa = plane_dist(pl, ax, ay, az);
-                uint32_t t = L.base[v];
+                uint32_t t = L.mp[v] & 0x7FFFu;
                 for (uint32_t mask = L.km[v]; mask; mask &= mask - 1u, ++t)
                 {
-                    const uint32_t u = r[__builtin_ctz(mask)];
+                    const uint32_t rw = S.re[lo0 + (uint32_t)__builtin_ctz(mask)], u = rw & 0xFFFFu;
                     const float bx = S.pos[3 * u], by = S.pos[3 * u + 1], bz = S.pos[3 * u + 2];
                     const float sb = plane_dist(pl, bx, by, bz);
                     // PlaneLineIntersection (:746-751): (a*sb - b*sa) * (1/(sb-sa))
@@ -200,15 +224,21 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
                     N.pos[3 * id] = (ax * sb - bx * sa) * inv;
                     N.pos[3 * id + 1] = (ay * sb - by * sa) * inv;
                     N.pos[3 * id + 2] = (az * sb - bz * sa) * inv;
-                    N.loff[id] = (uint16_t)lo; N.llen[id] = 3;
-                    N.ring[lo] = (uint16_t)(nKeep + L.pred[t]); N.ring[lo + 1] = (uint16_t)(nKeep + L.succ[t]); N.ring[lo + 2] = L.newidx[u];
+                    N.vw[id] = lo | (3u << 16);
+                    N.re[lo] = (nKeep + L.pred[t]) | (1u << 16); N.re[lo + 1] = (nKeep + L.succ[t]) | (0u << 16);
+                    N.re[lo + 2] = (uint32_t)L.mp[u] | (rw & 0xFFFF0000u);      // (the kept end lists this vertex where it listed v)
                 }
             }
         }
         nv = nKeep + M;
         cur ^= 1u;
         __syncthreads();
+        SC_STAMP(5);
+#ifdef SURTR_STAMP
+        if (lane == 0) L.tph[6] += 1;
+#endif
     }
+    SC_STAMP(1);
     *which = cur;
     if (lane == 0) L.nv[cur] = nv;
     __syncthreads();
@@ -219,7 +249,8 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
 __device__ inline int sc_park(const ScSolid& S, uint32_t nv, Shared& sh, uint32_t* cursors, float* apos, uint32_t* aloff, uint32_t* allen, int32_t* anbr,
                               uint32_t capV, uint32_t capH, uint32_t& voff, uint32_t& n, uint32_t& hoff, uint32_t& nh)
 {
-    const uint32_t H = (uint32_t)S.loff[nv - 1u] + S.llen[nv - 1u];
+    const uint32_t wl = S.vw[nv - 1u];
+    const uint32_t H = (wl & 0xFFFFu) + (wl >> 16);
     __syncthreads();
     if (threadIdx.x == 0) { sh.misc[0] = atomicAdd(&cursors[0], nv); sh.misc[1] = atomicAdd(&cursors[1], H); }
     __syncthreads();
@@ -230,10 +261,11 @@ __device__ inline int sc_park(const ScSolid& S, uint32_t nv, Shared& sh, uint32_
     {
         const size_t id = (size_t)voff + v;
         apos[3 * id] = S.pos[3 * v]; apos[3 * id + 1] = S.pos[3 * v + 1]; apos[3 * id + 2] = S.pos[3 * v + 2];
-        const uint32_t lo = hoff + S.loff[v], len = S.llen[v];
+        const uint32_t w = S.vw[v];
+        const uint32_t lo = hoff + (w & 0xFFFFu), len = w >> 16;
         aloff[id] = lo; allen[id] = len;
-        const uint16_t* r = S.ring + S.loff[v];
-        for (uint32_t q = 0; q < len; ++q) anbr[lo + q] = (int32_t)r[q];
+        const uint32_t* r = S.re + (w & 0xFFFFu);
+        for (uint32_t q = 0; q < len; ++q) anbr[lo + q] = (int32_t)(r[q] & 0xFFFFu);
     }
     n = nv; nh = H;
     __syncthreads();

@@ -238,7 +238,7 @@ struct surtr_ctx
     uint32_t n_wg_big = 48;          // workgroups of k_clip_pairs_big
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
     hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both
-    hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr, ev_cvx = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
     // pieces

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
                                                     uint32_t n_pairs, const uint8_t* __restrict__ outside,
                                                     ScratchPool pool, Arena A, PairRec* __restrict__ pairs,
                                                     const uint2* __restrict__ pair_list, uint32_t* __restrict__ porder,
-                                                    const uint32_t* __restrict__ pair_order)
+                                                    const uint32_t* __restrict__ pair_order, uint32_t front_par)
 {
     __shared__ Shared sh;
     __shared__ OneWaveLds U;
@@ -639,6 +639,10 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         const uint32_t f0 = plane_off[cell], F = plane_off[cell + 1] - f0;
         if (F > SURTR_MAXF) { rec.status = SURTR_E_INVALID; skip = true; }
         int err = 0;
+#ifdef SURTR_STAMP
+        const unsigned long long cx0 = __builtin_readcyclecounter();
+        unsigned long long cx1 = cx0, cx2 = cx0, cx3 = cx0;
+#endif
         if (!skip)
         {
             for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];
@@ -654,12 +658,18 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
             err = sliver ? SURTR_E_TOPOLOGY : small_clip(cin, F, sh, U.f, &which);
 #endif
             if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 80 : 81], 1u);       // (diagnostic: tasks the regular clipper took / handed on)
+#ifdef SURTR_STAMP
+            cx1 = __builtin_readcyclecounter();
+#endif
             if (err == 0)
             {
                 const uint32_t nv = U.f.nv[which];
                 if (nv != 0u) err = sc_park(U.f.buf[which], nv, sh, A.cursors, A.pos, A.loff, A.llen, A.nbr, A.capV, A.capH, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
             }
             __syncthreads();
+#ifdef SURTR_STAMP
+            cx2 = __builtin_readcyclecounter();
+#endif
             if (err == SC_FALLBACK)
             {
                 err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
@@ -689,7 +699,17 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
         }
         if (err == SURTR_E_TOPOLOGY) { rec.cv_bad = 1; rec.cv_off = 0; rec.cv_n = 1; rec.ch_off = 0; rec.ch_n = 0; err = 0; }
         if (err != 0) { rec.status = (uint32_t)err; rec.cv_n = 0; if (tid == 0) atomicMax(&A.cursors[5], (uint32_t)err); }
-        if (tid == 0) pairs[p] = rec;
+        if (tid == 0)
+        {
+            if (!front_par) pairs[p] = rec;
+            else
+            {
+                // k_prep_pairs runs beside this kernel and writes the img_* words of the same record: everything but those
+                PairRec& o = pairs[p];
+                o.cv_off = rec.cv_off; o.cv_n = rec.cv_n; o.ch_off = rec.ch_off; o.ch_n = rec.ch_n;
+                o.mv_off = 0; o.mv_n = 0; o.mh_off = 0; o.mh_n = 0; o.ni = 0; o.isl_off = 0; o.status = rec.status; o.cv_bad = rec.cv_bad;
+            }
+        }
         if (rec.cv_n != 0 && porder != nullptr)
         {
             // Cost class of the Mesh pre-pass of this pair, so that k_prep_pairs can start with the expensive ones: the
@@ -736,6 +756,21 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifdef SURTR_STAMP_SMALL
         if (tid == 0) for (int q = 0; q < 16; ++q) if (sh.ph[q]) atomicAdd(&g_stamp[q], sh.ph[q]);
 #endif
+#ifdef SURTR_STAMP
+        if (tid == 0)
+        {
+            // the slowest pair of the launch: where its time went (scripts/stamps_convex.py)
+            cx3 = __builtin_readcyclecounter();
+            const unsigned long long d = cx3 - cx0;
+            atomicAdd(&g_stamp2[32], d); atomicAdd(&g_stamp2[33], 1ull);
+            const unsigned long long old = atomicMax(&g_stamp2[34], d);
+            if (d > old)
+            {
+                g_stamp2[35] = cx1 - cx0; g_stamp2[36] = cx2 - cx1; g_stamp2[37] = cx3 - cx2; g_stamp2[38] = F;
+                for (int q = 0; q < 7; ++q) g_stamp2[40 + q] = U.f.tph[q];
+            }
+        }
+#endif
     }
 }
 
@@ -771,6 +806,7 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
     // the small tier of the record clipper (k_clip_pairs_rec): its table follows the half kernel's
     auto enqueue_small = [&](uint32_t p, uint32_t cls) { horder[(size_t)(16u + cls) * n_pairs + atomicAdd(&A.cursors[128u + cls], 1u)] = p; };
     const uint32_t tid = threadIdx.x;
+    const bool front_par = (rec_on & 4u) != 0u;
     char* sp = pool.base + (size_t)blockIdx.x * pool.per_wg;
     auto take = [&](size_t bytes) { char* r = sp; sp += (bytes + 255) & ~(size_t)255; return r; };
     uint32_t* needy = (uint32_t*)take((size_t)pool.VMAX * 4);
@@ -794,20 +830,30 @@ __device__ __attribute__((always_inline)) static inline void prep_pairs_body(Sha
         {
             // next ticket -> pair, expensive cost classes first (k_clip_convex filled porder with the pairs whose Convex survived)
             uint32_t t = atomicAdd(&A.cursors[9], 1u), pp = 0xFFFFFFFFu;
-            for (int cls = 15; cls >= 0; --cls)
-            {
-                const uint32_t cnt = A.cursors[48 + cls];
-                if (t < cnt) { pp = porder[(size_t)cls * n_pairs + t]; break; }
-                t -= cnt;
-            }
+            if (front_par) { if (t < n_pairs) pp = t; }      // (no queue: k_clip_convex is still running, see launch_event)
+            else
+                for (int cls = 15; cls >= 0; --cls)
+                {
+                    const uint32_t cnt = A.cursors[48 + cls];
+                    if (t < cnt) { pp = porder[(size_t)cls * n_pairs + t]; break; }
+                    t -= cnt;
+                }
             sh.misc[7] = pp;
         }
         __syncthreads();
         const uint32_t p = sh.misc[7];
         if (p >= n_pairs) break;
-        if (pairs[p].cv_n == 0 || pairs[p].status != 0) continue;
         const uint32_t cell = pair_list ? pair_list[p].x : cell_begin + p / P.n;
         const uint32_t piece = pair_list ? pair_list[p].y : p % P.n;
+        if (front_par)
+        {
+            // the Convex of this pair is being clipped beside this kernel: whether it is empty is not known yet.  The band of every pair
+            // is prepared (a pair whose Convex turns out empty is skipped by the clip kernels; its Mesh is outside the cell as well,
+            // as a rule found so by the sphere tests in a few steps), and the words of the record this kernel owns start from zero.
+            if (tid == 0) { pairs[p].img_fmt = IMG_NONE; pairs[p].img_off = 0; pairs[p].img_n = 0; pairs[p].img_h = 0; pairs[p].img_pc = 0; }
+            if (plane_off[cell + 1] - plane_off[cell] > SURTR_MAXF) continue;      // (k_clip_convex fails the pair with SURTR_E_INVALID)
+        }
+        else if (pairs[p].cv_n == 0 || pairs[p].status != 0) continue;
         const uint32_t m0 = P.mvo[piece], V = P.mvo[piece + 1] - m0;
         if (V < SURTR_PREP_MINV || V > pool.VMAX)
         {
@@ -1424,6 +1470,9 @@ __global__ __launch_bounds__(SURTR_S_THREADS) __attribute__((amdgpu_waves_per_eu
 #ifndef SURTR_MAIN_THREADS
 #define SURTR_MAIN_THREADS (2u * SURTR_WG)
 #endif
+#ifndef SURTR_CATCH_POLL
+#define SURTR_CATCH_POLL 8u       // workgroups of k_clip_pairs_catch that wait for hand-overs
+#endif
 #ifndef SURTR_WR_MAIN
 #define SURTR_WR_MAIN 3072u       // (a plane that needs more stages its originals in global memory: the lists get the room instead)
 #define SURTR_WNL_MAIN 3584u
@@ -1471,8 +1520,10 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                     t -= cnt;
                 }
             }
-            if (p == 0xFFFFFFFFu)
+            if (p == 0xFFFFFFFFu && (own ? blockIdx.x : 0u) < SURTR_CATCH_POLL)
             {
+                // (only the first few workgroups stay for the hand-overs -- a handful per event; the others give their LDS back to the
+                //  main kernel as soon as the irregular pairs are done)
                 own = false;
                 const uint32_t t = atomicAdd(&A.cursors[149], 1u);          // this workgroup's slot of the hand-over list
                 for (uint32_t spin = 0; t < hcap; ++spin)
@@ -2984,6 +3035,7 @@ int surtr_create(int device, surtr_ctx** out)
         hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_half, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_cvx, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { surtr_destroy(ctx); return SURTR_E_HIP; }
     *out = ctx;
@@ -3005,6 +3057,7 @@ void surtr_destroy(surtr_ctx* ctx)
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
     if (ctx->ev_half) (void)hipEventDestroy(ctx->ev_half);
+    if (ctx->ev_cvx) (void)hipEventDestroy(ctx->ev_cvx);
     if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
     if (ctx->ev_big) (void)hipEventDestroy(ctx->ev_big);
     for (int i = 0; i < 32; ++i) if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -3317,6 +3370,17 @@ static int ensure_arena(surtr_ctx* ctx, uint32_t n_pairs, uint64_t min_v = 0, ui
     return SURTR_OK;
 }
 
+// Start of an event: queue cursors and counters to zero, fragment status words to zero, hand-over list to "empty".
+__global__ void k_event_init(uint32_t* __restrict__ cursors, uint32_t* __restrict__ counts, uint32_t n_counts, uint32_t* __restrict__ frag_status,
+                             uint32_t n_status, uint32_t* __restrict__ hlist, uint32_t n_hlist)
+{
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    for (uint32_t i = i0; i < 256u; i += step) cursors[i] = 0u;
+    for (uint32_t i = i0; i < n_counts; i += step) counts[i] = 0u;
+    for (uint32_t i = i0; i < n_status; i += step) frag_status[i] = 0u;
+    for (uint32_t i = i0; i < n_hlist; i += step) hlist[i] = 0xFFFFFFFFu;
+}
+
 static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pairs)
 {
     if (ctx->cap_pair_order < n_pairs)
@@ -3337,6 +3401,9 @@ static int upload_pair_order(surtr_ctx* ctx, const uint32_t* ord, uint32_t n_pai
 #endif
 #ifndef SURTR_REC_MAXN
 #define SURTR_REC_MAXN 2304u
+#endif
+#ifndef SURTR_FRONT_PAR_MAX
+#define SURTR_FRONT_PAR_MAX 1024u      // pairs of an event up to which k_clip_convex and the pre-pass kernel run side by side
 #endif
 static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, const uint2* d_pair_list, const uint8_t* outside, uint32_t flags)
 {
@@ -3360,9 +3427,18 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     rc = ensure_prep(ctx, std::max(n_pairs, 1u), std::max(n_wg_prep, ctx->n_wg_prep));
     if (rc) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(ctx->arena.cursors, 0, 1024, st));
-    HIPCHK(hipMemsetAsync(ctx->d_counts, 0, sizeof(surtr_counts), st));
-    HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
+    // (the event's zeroes and the hand-over list's "empty" words in one launch, not four fills with a few microseconds between each)
+    const uint32_t hcap = n_pairs + 4096u;
+    if (ctx->cap_hlist < hcap)
+    {
+        HIPCHK(hipStreamSynchronize(st));      // (a previous event may still read the list)
+        free_dev(ctx->d_hlist); ctx->d_hlist = nullptr; ctx->cap_hlist = 0;
+        HIPCHK(hipMalloc((void**)&ctx->d_hlist, (size_t)hcap * 4));
+        ctx->cap_hlist = hcap;
+    }
+    static_assert(sizeof(surtr_counts) % 4 == 0, "surtr_counts is cleared by words");
+    hipLaunchKernelGGL(k_event_init, dim3(SURTR_LANES == 1 ? 1 : 64), dim3(SURTR_LANES == 1 ? 1 : 256), 0, st, ctx->arena.cursors, (uint32_t*)ctx->d_counts,
+                       (uint32_t)(sizeof(surtr_counts) / 4), ctx->d_frag_status, ctx->cap_frags, ctx->d_hlist, hcap);
     const uint8_t* d_out = nullptr;
     ctx->last_outside.clear();
     if (outside) ctx->last_outside.assign(outside, outside + ctx->n_pieces);
@@ -3395,11 +3471,6 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         }
         d_pair_order = ctx->d_pair_order;
     }
-    PROF_BEGIN(6);
-    if (n_pairs)
-        hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order);
-    PROF_END(6);
     uint32_t big_quota = ctx->wave_big ? 0xFFFFFFFFu : 2u * ctx->n_wg_big;
     if (const char* e = getenv("SURTR_BIG_QUOTA")) big_quota = (uint32_t)atoi(e);      // (tests: 0 sends every big band to the regular kernel's global scratch)
     // (pieces of 80 000 vertices and more: bands beyond this size go to the whole-CU record clipper, see k_prep_pairs)
@@ -3446,19 +3517,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     //  64 and more take LDS from it: 2.50 / 2.50 / 2.56 ms per event with 16 / 32 / 64)
     uint32_t n_catch = std::min(std::min(ctx->n_wg_catch, 32u), std::max(n_pairs, 1u));
     if (const char* e = getenv("SURTR_CATCH_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_catch) n_catch = v; }
-    const uint32_t hcap = n_pairs + 4096u;
     uint32_t heavy_need = 0u;      // (off: k_clip_pairs_big takes 2 x its grid of such pairs and no more -- the rest would land on the catcher)
     if (const char* e = getenv("SURTR_HEAVY_NEED")) { if (split_on) heavy_need = (uint32_t)atoi(e); }
-    if (split_on)
-    {
-        if (ctx->cap_hlist < hcap)
-        {
-            free_dev(ctx->d_hlist); ctx->d_hlist = nullptr;
-            HIPCHK(hipMalloc((void**)&ctx->d_hlist, (size_t)hcap * 4));
-            ctx->cap_hlist = hcap;
-        }
-        HIPCHK(hipMemsetAsync(ctx->d_hlist, 0xFF, (size_t)hcap * 4, st));
-    }
     uint32_t n_wg_rec = 0;
     if (small_cap)
     {
@@ -3472,11 +3532,35 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
             HIPCHK(hipMalloc((void**)&ctx->pool_rec.base, per * n_wg_rec));
         }
     }
-    PROF_BEGIN(7);
     // measured on blocks of configs[3]: 512 pairs 0.60 -> 0.23 ms, 1 024 pairs 0.70 -> 0.37, 2 048 pairs 0.77 -> 0.68, 4 096 pairs 0.96 -> 1.32
     uint32_t wide_max = 4u * ctx->max_wg;
     if (const char* e = getenv("SURTR_PREP_WIDE_MAX")) wide_max = (uint32_t)atoi(e);
+    // The clip of the Convexes and the pre-pass of the Meshes are independent but for two things: the pre-pass skips the pairs whose
+    // Convex came out empty, and takes the others from a queue by estimated cost that k_clip_convex builds.  An event of so few pairs
+    // that every pair finds a free workgroup at once needs neither -- there the two kernels run side by side (front_par: the
+    // pre-pass takes the pairs by index and prepares the empty ones too; the clip kernels wait for both and skip those).
+    // Measured per event, one at a time: configs[1] 0.64 -> 0.58 ms, configs[2] 0.92 -> 0.875; not for the wide pre-pass of a block
+    // of large pieces (1 024 threads a pair: beside k_clip_convex it takes twice as long, 512-cell block of configs[3] 1.16 -> 1.19 ms)
+    // nor for events whose pairs queue up (configs[3]: 2.47 -> 2.71 ms, the cost order and the 761 skipped pairs are worth more).
     const bool prep_wide = n_pairs != 0 && n_pairs <= wide_max && ctx->vmax >= 8192u;      // few pairs, large meshes
+    bool front_par = n_pairs != 0 && n_pairs <= SURTR_FRONT_PAR_MAX && !prep_wide;
+    if (const char* e = getenv("SURTR_FRONT_PAR")) front_par = n_pairs != 0 && atoi(e) != 0;
+    hipStream_t st_cvx = st;
+    if (front_par)
+    {
+        rec_on |= 4u;
+        st_cvx = ctx->stream3;
+        HIPCHK(hipEventRecord(ctx->ev_prep, st));      // (behind the memsets above)
+        HIPCHK(hipStreamWaitEvent(st_cvx, ctx->ev_prep, 0));
+    }
+    PROF_BEGIN_ON(6, st_cvx);
+    if (n_pairs)
+        hipLaunchKernelGGL(k_clip_convex, dim3(n_wg_small), dim3(SURTR_LANES), 0, st_cvx, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           d_out, ctx->pool_small, ctx->arena, ctx->d_pairs, d_pair_list, front_par ? (uint32_t*)nullptr : ctx->d_order + (size_t)16 * ctx->cap_order, d_pair_order,
+                           front_par ? 1u : 0u);
+    PROF_END_ON(6, st_cvx);
+    if (front_par) HIPCHK(hipEventRecord(ctx->ev_cvx, st_cvx));
+    PROF_BEGIN(7);
     if (n_pairs && prep_wide)
         hipLaunchKernelGGL(k_prep_pairs_wide, dim3(n_wg_prep), dim3(SURTR_WG_WIDE), 0, st, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->prep, ctx->arena, ctx->img, std::min((uint32_t)SURTR_LV, ctx->pool.CV), std::min((uint32_t)SURTR_LVS, ctx->pool_half.CV), ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)16 * ctx->cap_order,
@@ -3492,25 +3576,33 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_END(7);
     // k_clip_pairs_big goes first on the caller's stream, right behind k_prep_pairs, so that its few whole-CU workgroups
     // are placed before k_clip_pairs (second stream) and k_clip_pairs_half (third) fill the CUs; all three run side by side.
+    // (front_par: the main kernel stays on the caller's stream and the whole-CU kernel goes to the second -- every wait of one
+    //  stream for another costs some 12 us, and there the main kernel is the critical path: it then waits only for k_clip_convex)
     hipStream_t st2 = ctx->stream2, st3 = ctx->stream3;
+    hipStream_t st_main = front_par ? st : st2, st_bigk = front_par ? st2 : st;
     HIPCHK(hipEventRecord(ctx->ev_prep, st));
     HIPCHK(hipStreamWaitEvent(st2, ctx->ev_prep, 0));
     HIPCHK(hipStreamWaitEvent(st3, ctx->ev_prep, 0));
-    PROF_BEGIN(8);
+    if (front_par)
+    {
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_cvx, 0));      // (stream3 has k_clip_convex in order)
+        HIPCHK(hipStreamWaitEvent(st2, ctx->ev_cvx, 0));
+    }
+    PROF_BEGIN_ON(8, st_bigk);
     uint32_t walk0 = SURTR_WWALK0;
     if (const char* e = getenv("SURTR_WWALK0")) { const int v = atoi(e); if (v >= 0 && v <= 64) walk0 = (uint32_t)v; }
     if (n_pairs && ctx->wave_big)
-        hipLaunchKernelGGL(k_clip_pairs_wave_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
+        hipLaunchKernelGGL(k_clip_pairs_wave_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st_bigk, P, ctx->d_planes,
                            ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, 15, 14, 11u, walk0);
     else if (n_pairs)
-        hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st, P, ctx->d_planes,
+        hipLaunchKernelGGL(k_clip_pairs_big, dim3(std::min(ctx->n_wg_big, std::max(n_pairs, 1u))), dim3(SURTR_WG), 0, st_bigk, P, ctx->d_planes,
                            ctx->d_plane_off, cell_begin, n_pairs, ctx->pool, max_wg, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order);
-    PROF_END(8);
+    PROF_END_ON(8, st_bigk);
     // the regular pairs on one wave each (wave_clip.h); what it hands on comes back through the retry launch below
     // (measured on blocks of configs[3]: the record clipper wins once the pairs queue up -- 4 096 pairs 1.88 -> 1.65 ms, 2 048 pairs
     // 2.35 -> 2.30 ms for the event -- and loses when every pair has a workgroup to itself: 1 024 pairs 1.63 -> 1.69 ms, 512 pairs
     // 1.33 -> 1.45 ms; its loader sorts the band, which the general clipper's image copy does not have to)
-    hipStream_t st_rec = st2;
+    hipStream_t st_rec = st_main;
     if (getenv("SURTR_SMALL_CONC")) st_rec = st3;      // (timing experiment only: the large tier then misses late hand-overs)
     PROF_BEGIN_ON(12, st_rec);
     if (n_pairs && wave_on && small_cap)
@@ -3518,25 +3610,25 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->pool_rec, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list,
                            (const uint32_t*)(ctx->d_order + (size_t)32 * ctx->cap_order + (size_t)16 * n_pairs), ctx->d_order, walk0);
     PROF_END_ON(12, st_rec);
-    PROF_BEGIN_ON(11, st2);
-    if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st2);
+    PROF_BEGIN_ON(11, st_main);
+    if (n_pairs && wave_on) PROF_HIST_BEGIN(11, st_main);
     uint32_t n_wg_main = n_wg;
     if (const char* e = getenv("SURTR_MAIN_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= max_wg) n_wg_main = v; }
     if (n_pairs && wave_on && split_on)
-        hipLaunchKernelGGL(k_clip_pairs_main, dim3(n_wg_main), dim3(SURTR_MAIN_THREADS), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+        hipLaunchKernelGGL(k_clip_pairs_main, dim3(n_wg_main), dim3(SURTR_MAIN_THREADS), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, walk0);
     else if (n_pairs && wave_on)
-        hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+        hipLaunchKernelGGL(k_clip_pairs_wave, dim3(n_wg), dim3(SURTR_WG), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u, walk0);
-    if (n_pairs && wave_on) PROF_HIST_END(11, st2);
-    PROF_END_ON(11, st2);
-    PROF_BEGIN_ON(0, st2);
-    if (n_pairs && !wave_on) PROF_HIST_BEGIN(0, st2);
+    if (n_pairs && wave_on) PROF_HIST_END(11, st_main);
+    PROF_END_ON(11, st_main);
+    PROF_BEGIN_ON(0, st_main);
+    if (n_pairs && !wave_on) PROF_HIST_BEGIN(0, st_main);
     if (n_pairs && !wave_on)
-        hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+        hipLaunchKernelGGL(k_clip_pairs, dim3(n_wg), dim3(SURTR_WG), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, 13, 0, 4u);
-    if (n_pairs && !wave_on) PROF_HIST_END(0, st2);
-    PROF_END_ON(0, st2);
+    if (n_pairs && !wave_on) PROF_HIST_END(0, st_main);
+    PROF_END_ON(0, st_main);
     PROF_BEGIN_ON(13, st3);
     if (n_pairs && wave_on && split_on)
         hipLaunchKernelGGL(k_clip_pairs_catch, dim3(n_catch), dim3(SURTR_WG), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
@@ -3548,15 +3640,15 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
                            ctx->pool_half, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order + (size_t)32 * ctx->cap_order);
     PROF_END_ON(9, st3);
     HIPCHK(hipEventRecord(ctx->ev_half, st3));
-    HIPCHK(hipStreamWaitEvent(st2, ctx->ev_half, 0));
+    HIPCHK(hipStreamWaitEvent(st_main, ctx->ev_half, 0));
     // the pairs that outgrew the half-size topology (class 0, normally none): the regular kernel once more, behind both
     // (it reuses the scratch slots of the first launch)
-    PROF_BEGIN_ON(10, st2);
+    PROF_BEGIN_ON(10, st_main);
     if (n_pairs && use_half)
-        hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st2, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+        hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
-    PROF_END_ON(10, st2);
-    HIPCHK(hipEventRecord(ctx->ev_big, st2));
+    PROF_END_ON(10, st_main);
+    HIPCHK(hipEventRecord(ctx->ev_big, st2));      // (the main kernel's stream, or the whole-CU kernel's when the main one runs on `st`)
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
     PROF_BEGIN(1);
     hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,

@@ -30,7 +30,9 @@ def _quad_torus(nu=40, nv=24, R=1.0, r=0.35):
 
 
 @pytest.mark.parametrize("env", [{}, {"SURTR_REC_MAXN": "100000"}, {"SURTR_REC": "0"}, {"SURTR_PREP_SORTED": "0"},
-                                 {"SURTR_SMALL": "1", "SURTR_REC_MAXN": "100000"}])
+                                 {"SURTR_SMALL": "1", "SURTR_REC_MAXN": "100000"},
+                                 # (an event of 256 pairs clips the Convexes and prepares the bands side by side: here one after the other)
+                                 {"SURTR_FRONT_PAR": "0"}])
 def test_sorted_prepass_emulation_equals_oracle(emul_engine, oracle, monkeypatch, env):
     monkeypatch.setenv("SURTR_WAVE", "1")
     for k, v in env.items():
@@ -80,7 +82,9 @@ def test_faces_that_are_no_triangles_take_the_face_walks(emul_engine, oracle, mo
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{}, {"SURTR_REC_MAXN": "100000"}, {"SURTR_REC": "0"}, {"SURTR_PREP_SORTED": "0"}, {"SURTR_SMALL": "1"}])
+@pytest.mark.parametrize("env", [{}, {"SURTR_REC_MAXN": "100000"}, {"SURTR_REC": "0"}, {"SURTR_PREP_SORTED": "0"}, {"SURTR_SMALL": "1"},
+                                 # (the arrangement of small events -- k_clip_convex beside the pre-pass kernel -- on the large one)
+                                 {"SURTR_FRONT_PAR": "1"}])
 def test_torus_4096_digest_whatever_the_prepass(gpu_engine, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
