@@ -2332,10 +2332,11 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
     __shared__ uint16_t f_loff[FL_V]; __shared__ uint16_t f_llen[FL_V]; __shared__ uint16_t f_nbr[FL_H];
     // the sliver path's visit marks, or (regular fragments of at most FL_J half-edges) the pointer-jumping arrays
     struct IrrLds { uint8_t vis[FL_H]; uint32_t cov[FL_H]; };
-    struct JumpLds { uint16_t k0[FL_J], k1[FL_J], x0[FL_J], x1[FL_J]; };
+    struct JumpLds { uint16_t k0[FL_J], k1[FL_J], x0[FL_J], x1[FL_J], d1[FL_J]; };      // (the other distance array is the unused upper half of f_nbr)
     struct EarLds { float pos[3 * FL_V]; uint16_t loop[FL_J]; };       // once the faces are known: positions and face loops for the ear clippers
     union FacesLds { IrrLds irr; JumpLds jmp; EarLds ear; };
     static_assert(sizeof(EarLds) <= sizeof(IrrLds), "the ear staging reuses the bytes of the face search");
+    static_assert(sizeof(JumpLds) <= sizeof(IrrLds), "the pointer-jumping arrays fit the bytes of the irregular path");
     __shared__ FacesLds FU;
     uint8_t* const f_vis = FU.irr.vis; uint32_t* const f_cov = FU.irr.cov;
     const uint32_t tid = threadIdx.x;
@@ -2397,7 +2398,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
         auto gLN = [&](uint32_t v) -> uint32_t { return llen[v]; };
         auto lLO = [&](uint32_t v) -> uint32_t { return f_loff[v]; };
         auto lLN = [&](uint32_t v) -> uint32_t { return f_llen[v]; };
-        auto successors = [&](auto LO, auto LN, const auto* NB, auto* NX, auto* KEY) {
+        auto successors = [&](auto LO, auto LN, const auto* NB, auto* NX, auto* KEY, int32_t* copy) {
             typedef typename std::remove_reference<decltype(NX[0])>::type XT;
             bool dup = false;
             for (uint32_t v = tid; v < n; v += group_size())
@@ -2413,13 +2414,14 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
                     const uint32_t sq = (q == 0) ? nbq - 1 : q - 1;   // FaceLoop
                     NX[lo + s] = (XT)(lb + sq);
                     KEY[lo + s] = (XT)(lo + s);
+                    if (copy != nullptr) copy[lo + s] = (int32_t)(lb + sq);
                 }
             }
             if (dup) sh.flagBad = 1;
         };
-        if (jump_lds) successors(lLO, lLN, f_nbr, FU.jmp.x0, FU.jmp.k0);
-        else if (topo_lds) successors(lLO, lLN, f_nbr, nxA, keyA);
-        else successors(gLO, gLN, nbr, nxA, keyA);
+        if (jump_lds) successors(lLO, lLN, f_nbr, FU.jmp.x0, FU.jmp.k0, nxA);      // (nxA: the successors as they are, for the checks after the jumps)
+        else if (topo_lds) successors(lLO, lLN, f_nbr, nxA, keyA, (int32_t*)nullptr);
+        else successors(gLO, gLN, nbr, nxA, keyA, (int32_t*)nullptr);
         __syncthreads();
         STAMP(60);
         bool irregular = sh.flagBad != 0;
@@ -2436,6 +2438,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
         {
         nfaces = 0; lensum = 0; faceLo = nxB; faceLen = keyB; serial_extract = false; kc = keyA;
         const uint16_t* own16 = nullptr;      // LDS pointer jumping: per half-edge the smallest half-edge of its loop
+        const uint16_t* dist16 = nullptr;     // ... and its distance to it along the loop
+        uint16_t* free16a = nullptr; uint16_t* free16b = nullptr;      // the jump pointers' arrays, dead after the jumps
         staged = irregular && n <= FL_V && H <= FL_H;
         bool pinched = false;
         if (irregular)
@@ -2516,20 +2520,29 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
         else if (jump_lds)
         {
             // 2. minimum half-edge id of every loop by pointer jumping, on the LDS arrays
+            // ... and, with it, the distance of every half-edge to that minimum along the loop (list ranking): a window of
+            // 2^i successors per half-edge holds its smallest id and how far ahead it lies; when the window of e's 2^i-th
+            // successor has a smaller one, that lies 2^i further.  Once the windows cover the loops, every half-edge knows its
+            // face (the minimum = the half-edge ExtractFaces starts the face with) and its place in it -- no walk.
             uint16_t* k16 = FU.jmp.k0; uint16_t* kn = FU.jmp.k1; uint16_t* xc = FU.jmp.x0; uint16_t* xn = FU.jmp.x1;
+            uint16_t* dc = f_nbr + FL_J; uint16_t* dn = FU.jmp.d1;
+            for (uint32_t e = tid; e < H; e += group_size()) dc[e] = 0;
+            __syncthreads();
             for (uint32_t span = 1; span < H; span <<= 1)
             {
                 for (uint32_t e = tid; e < H; e += group_size())
                 {
                     const uint32_t t = xc[e];
                     const uint16_t a = k16[e], b = k16[t];
-                    kn[e] = a < b ? a : b;
+                    const uint16_t da = dc[e], db = dc[t];
+                    kn[e] = a <= b ? a : b;
+                    dn[e] = a <= b ? da : (uint16_t)(db + span);
                     xn[e] = xc[t];
                 }
                 __syncthreads();
-                uint16_t* t1 = k16; k16 = kn; kn = t1; t1 = xc; xc = xn; xn = t1;
+                uint16_t* t1 = k16; k16 = kn; kn = t1; t1 = xc; xc = xn; xn = t1; t1 = dc; dc = dn; dn = t1;
             }
-            own16 = k16;
+            own16 = k16; dist16 = dc; free16a = xc; free16b = xn;
             STAMP(61);
         }
         else
@@ -2600,8 +2613,65 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
                 }
                 return true;
             };
+            // The same from the ranks of the LDS pointer jumping: a face's length is the distance of its first half-edge's successor
+            // + 1, its vertices are the sources of its half-edges at (length - distance).  That holds when every loop is a simple
+            // cycle that passes through no vertex twice (the reference closes a face at the start VERTEX, :100-118); the checks
+            // below say so, and a fragment that fails one takes the path of the irregular ones (pinched).
+            auto owners_ranked = [&]() -> bool {
+                auto vertex_of = [&](uint32_t e) -> uint32_t {
+                    uint32_t lo_v = 0, hi_v = n;
+                    while (hi_v - lo_v > 1) { const uint32_t mid = (lo_v + hi_v) >> 1; if (f_loff[mid] <= e) lo_v = mid; else hi_v = mid; }
+                    return lo_v;
+                };
+                bool bad = false;
+                for (uint32_t e = tid; e < H; e += group_size())
+                {
+                    const uint32_t t = (uint32_t)nxA[e], o = own16[e];
+                    if (t >= H || own16[t] != o) { bad = true; continue; }
+                    const uint32_t want = o == e ? 0u : (t == o ? 1u : (uint32_t)dist16[t] + 1u);
+                    if ((uint32_t)dist16[e] != want) bad = true;
+                }
+                for (uint32_t v = tid; v < n; v += group_size())
+                {
+                    const uint32_t lo = f_loff[v], len = f_llen[v];
+                    for (uint32_t s1 = 1; s1 < len; ++s1)
+                        for (uint32_t s2 = 0; s2 < s1; ++s2) if (own16[lo + s1] == own16[lo + s2]) bad = true;
+                }
+                if (bad) sh.flagBad = 3;
+                __syncthreads();
+                if (sh.flagBad == 3) { pinched = true; return true; }
+                auto ownfn = [&](uint32_t e) -> uint2 {
+                    if ((uint32_t)own16[e] != e) return make_uint2(0u, 0u);
+                    return make_uint2(1u, (uint32_t)dist16[(uint32_t)nxA[e]] + 1u);
+                };
+                scan_blocks(H, blk, sh, ownfn, nfaces, lensum);
+                if (lensum != H) { pinched = true; return true; }
+                uint16_t* lo_of = free16a; uint16_t* len_of = free16b;
+                const uint32_t nb = (H + SURTR_LANES - 1u) >> SURTR_LSH;
+                for (uint32_t b = wave_id(); b < nb; b += group_waves())
+                {
+                    const uint32_t e = (b << SURTR_LSH) + lane_id();
+                    uint2 c = make_uint2(0u, 0u);
+                    if (e < H) c = ownfn(e);
+                    const uint2 ex = wave_excl2(c);
+                    if (e < H && c.x)
+                    {
+                        const uint32_t fi = blk[b].x + ex.x, lo = blk[b].y + ex.y;
+                        faceLo[fi] = (int32_t)lo; faceLen[fi] = (int32_t)c.y;
+                        lo_of[e] = (uint16_t)lo; len_of[e] = (uint16_t)c.y;
+                    }
+                }
+                __syncthreads();
+                for (uint32_t e = tid; e < H; e += group_size())
+                {
+                    const uint32_t o = own16[e], d = dist16[e];
+                    loopbuf[(uint32_t)lo_of[o] + (d == 0u ? 0u : (uint32_t)len_of[o] - d)] = (int32_t)vertex_of(e);
+                }
+                return true;
+            };
             bool ok;
-            if (own16 != nullptr) ok = owners(lLO, lLN, f_nbr, [&](uint32_t e) { return (uint32_t)own16[e] == e; });
+            if (own16 != nullptr && dist16 != nullptr) ok = owners_ranked();
+            else if (own16 != nullptr) ok = owners(lLO, lLN, f_nbr, [&](uint32_t e) { return (uint32_t)own16[e] == e; });
             else if (topo_lds) ok = owners(lLO, lLN, f_nbr, [&](uint32_t e) { return kc[e] == (int32_t)e; });
             else ok = owners(gLO, gLN, nbr, [&](uint32_t e) { return kc[e] == (int32_t)e; });
             if (!ok) { failed = true; break; }
