@@ -119,9 +119,14 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             L.c[v] = (int8_t)c;
             zero = zero || c == 0; cut = cut || c < 0; keep = keep || c > 0;
         }
+        // (:303-328: "below" = no vertex strictly inside, tested first; "above" = none strictly outside.  Vertices in the plane
+        //  matter only when the plane cuts: a slab plane through an extreme vertex of the solid is "above" like any other)
+        // (every vertex in the plane -- a flat solid: the reference's answer then depends on its bounding-box shortcut, :297-301;
+        //  the general clipper has that case)
+        const bool anyCut = __ballot(cut) != 0ull;
+        if (__ballot(keep) == 0ull) { if (!anyCut) return SC_FALLBACK; nv = 0; break; }      // "below": everything goes (:322-327)
+        if (!anyCut) continue;                                       // "above": nothing to do (the solid has >= 4 vertices)
         if (__ballot(zero) != 0ull) return SC_FALLBACK;
-        if (__ballot(cut) == 0ull) continue;                         // "above": nothing to do (the solid has >= 4 vertices)
-        if (__ballot(keep) == 0ull) { nv = 0; break; }               // "below": everything goes (:322-327)
         __syncthreads();
         SC_STAMP(1);
         // ---- new vertices in (clipped vertex, slot) order; kept vertices' new indices and ring offsets ----

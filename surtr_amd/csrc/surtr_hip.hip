@@ -1704,8 +1704,8 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
     __shared__ ArgF slotF[SURTR_NWAVE];
     __shared__ ArgD slotD[SURTR_NWAVE];
     __shared__ float nrm[4][3];
-    __shared__ LdsTopoSmall L;
-    __shared__ LdsWorkSmall W;
+    __shared__ OneWaveLds U;      // (the one-wave clipper of regular planes shares the bytes of the general one's arrays)
+    LdsTopoSmall& L = U.g.L; LdsWorkSmall& W = U.g.W;
     Scratch S = carve(pool, blockIdx.x);
     const uint32_t tid = threadIdx.x;
     const uint32_t nf = counts->n_frag;
@@ -1844,6 +1844,18 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         int err = SURTR_E_TOPOLOGY;      // a sliver Convex: the literal clipper below, from the start
         if (!solid_is_sliver(cin))
         {
+            // the regular clipper first: it takes the Convex whose slab planes either cut no vertex (the plane through an extreme
+            // vertex of the fragment that is an extreme vertex of its Convex too) or cut with no vertex in the plane
+            uint32_t which = 0;
+            err = small_clip(cin, 8, sh, U.f, &which);
+            if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 82 : 83], 1u);       // (diagnostic: refits the regular clipper took / handed on)
+            if (err == 0)
+            {
+                const uint32_t nv = U.f.nv[which];
+                if (nv != 0u) err = sc_park(U.f.buf[which], nv, sh, A.cursors, A.pos, A.loff, A.llen, A.nbr, A.capV, A.capH, nvoff, ncn, nhoff, nchn);
+            }
+            __syncthreads();
+            if (err == SC_FALLBACK)
             err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
                 if (T.nLive == 0) return 0;
                 return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
