@@ -9,5 +9,5 @@ for name, sc, n in (("blob64", S.blob_scene(64), 64), ("blob1024", S.blob_scene(
     c = eng.fracture_event(0, n)
     qs = eng.queue_stats()
     fo = np.asarray(sc["face_off"]); 
-    print(name, "convex verts", len(sc["convex"]["pos"]) if isinstance(sc["convex"], dict) else "?", "small clip took", qs[80], "fell back", qs[81], "| refit: took", qs[82], "fell back", qs[83], "faces per cell: mean %.1f max %d" % (np.diff(fo).mean(), np.diff(fo).max()))
+    print(name, "convex verts", len(sc["convex"]["pos"]) if isinstance(sc["convex"], dict) else "?", "small clip took", qs[80], "fell back", qs[81], "| refit: took", qs[82], "fell back", qs[83], "| general clips resumed from a later plane: convex", qs[78], "refit", qs[79], "faces per cell: mean %.1f max %d" % (np.diff(fo).mean(), np.diff(fo).max()))
 eng.close()

@@ -51,7 +51,10 @@ struct ScLds
 
 // Clips `in` by sh.planes[0..F).  0: done, the result is L.buf[*which] with L.nv[*which] vertices (0 = empty);
 // SC_FALLBACK: use the general clipper.  One wave; every lane must call it.
-__device__ inline int small_clip(const SolidIn in, const uint32_t F, const Shared& sh, ScLds& L, uint32_t* which)
+// stop (optional): with SC_FALLBACK, the plane it stopped at when the solid before that plane -- L.buf[*which], L.nv[*which]
+// vertices, exactly the reference's compacted solid after the planes before (:464-495) -- is there for the general clipper to go
+// on from (sc_stage); 0xFFFFFFFF when there is none (the input itself is not regular).
+__device__ inline int small_clip(const SolidIn in, const uint32_t F, const Shared& sh, ScLds& L, uint32_t* which, uint32_t* stop = nullptr)
 {
     const uint32_t lane = lane_id();
     const uint32_t V = in.nv;
@@ -62,6 +65,7 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
 #else
 #define SC_STAMP(i) do { } while (0)
 #endif
+    if (stop != nullptr) *stop = 0xFFFFFFFFu;
     if (V == 0 || V > SC_V) return SC_FALLBACK;
     const uint32_t hbase = in.loff[0], H = in.loff[V - 1u] + in.llen[V - 1u] - hbase;
     if (H > SC_H) return SC_FALLBACK;
@@ -106,6 +110,8 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
     if (__ballot(odd) != 0ull) return SC_FALLBACK;
     __syncthreads();
     SC_STAMP(0);
+    // (nothing of L.buf[cur] has been touched when a plane gives up: the next solid is written to the other buffer)
+#define SC_GIVE_UP do { if (stop != nullptr) { *stop = k; *which = cur; if (lane == 0) L.nv[cur] = nv; __syncthreads(); } return SC_FALLBACK; } while (0)
     uint32_t cur = 0, nv = V;
     for (uint32_t k = 0; k < F && nv != 0u; ++k)
     {
@@ -124,9 +130,9 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         // (every vertex in the plane -- a flat solid: the reference's answer then depends on its bounding-box shortcut, :297-301;
         //  the general clipper has that case)
         const bool anyCut = __ballot(cut) != 0ull;
-        if (__ballot(keep) == 0ull) { if (!anyCut) return SC_FALLBACK; nv = 0; break; }      // "below": everything goes (:322-327)
+        if (__ballot(keep) == 0ull) { if (!anyCut) SC_GIVE_UP; nv = 0; break; }      // "below": everything goes (:322-327)
         if (!anyCut) continue;                                       // "above": nothing to do (the solid has >= 4 vertices)
-        if (__ballot(zero) != 0ull) return SC_FALLBACK;
+        if (__ballot(zero) != 0ull) SC_GIVE_UP;
         __syncthreads();
         SC_STAMP(1);
         // ---- new vertices in (clipped vertex, slot) order; kept vertices' new indices and ring offsets ----
@@ -156,7 +162,7 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
             carryM += tx & 0xFFFFu; carryK += tx >> 16; carryH += ty;
         }
         const uint32_t M = carryM, nKeep = carryK, HK = carryH;
-        if (nKeep + M > SC_V || HK + 3u * M > SC_H) return SC_FALLBACK;
+        if (nKeep + M > SC_V || HK + 3u * M > SC_H) SC_GIVE_UP;
         if (nKeep + M < 4u) { nv = 0; break; }                        // (:497-499)
         for (uint32_t t = lane; t < M; t += SURTR_LANES) L.pred[t] = 0xFFFFu;
         __syncthreads();
@@ -187,12 +193,12 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
                 L.pred[end] = (uint16_t)t;                             // two walks ending on `end`: one of them does not find itself below
             }
         }
-        if (__ballot(bad) != 0ull) return SC_FALLBACK;
+        if (__ballot(bad) != 0ull) SC_GIVE_UP;
         __syncthreads();
         SC_STAMP(3);
         // (pred == succ: a cap of two vertices, i.e. a new ring that lists a vertex twice)
         for (uint32_t t = lane; t < M; t += SURTR_LANES) if (L.pred[t] == 0xFFFFu || L.pred[L.succ[t]] != t || L.pred[t] == L.succ[t]) bad = true;
-        if (__ballot(bad) != 0ull) return SC_FALLBACK;
+        if (__ballot(bad) != 0ull) SC_GIVE_UP;
         SC_STAMP(4);
         // ---- the solid after this plane, compacted (:464-495): kept vertices in order, then the new ones ----
         for (uint32_t v = lane; v < nv; v += SURTR_LANES)
@@ -243,11 +249,28 @@ __device__ inline int small_clip(const SolidIn in, const uint32_t F, const Share
         if (lane == 0) L.tph[6] += 1;
 #endif
     }
+#undef SC_GIVE_UP
     SC_STAMP(1);
     *which = cur;
     if (lane == 0) L.nv[cur] = nv;
     __syncthreads();
     return 0;
+}
+
+// The solid small_clip stopped with, as an input of the general clipper: positions and rings into global staging arrays
+// (`ring` is indexed by the offsets written to `loff`).  One wave; ends with a barrier.
+__device__ inline SolidIn sc_stage(const ScSolid& S, uint32_t nv, float* pos, uint32_t* loff, uint32_t* llen, uint32_t* ring)
+{
+    for (uint32_t v = lane_id(); v < nv; v += SURTR_LANES)
+    {
+        pos[3 * v] = S.pos[3 * v]; pos[3 * v + 1] = S.pos[3 * v + 1]; pos[3 * v + 2] = S.pos[3 * v + 2];
+        const uint32_t w = S.vw[v], lo = w & 0xFFFFu, len = w >> 16;
+        loff[v] = lo; llen[v] = len;
+        for (uint32_t q = 0; q < len; ++q) ring[lo + q] = S.re[lo + q] & 0xFFFFu;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return SolidIn{pos, loff, llen, (const int32_t*)ring, nv, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 
 // Writes the result of small_clip to the arena as one packed solid (the layout park_topo writes).  One wave.

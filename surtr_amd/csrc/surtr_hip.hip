@@ -25,6 +25,9 @@
 
 #include "surtr_ctx.h"
 #include "small_clip.h"
+#ifndef SC_RESUME
+#define SC_RESUME 1      // the general one-wave clipper goes on from the plane small_clip stopped at (0: from the input, as in round 3)
+#endif
 #include "literal_clip.h"
 #include "wave_clip.h"
 #include "prep_sorted.h"
@@ -655,7 +658,8 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #ifdef SURTR_NO_SMALL_CLIP      // (diagnostic builds: the general clipper alone)
             err = SC_FALLBACK;
 #else
-            err = sliver ? SURTR_E_TOPOLOGY : small_clip(cin, F, sh, U.f, &which);
+            uint32_t stop = 0xFFFFFFFFu;
+            err = sliver ? SURTR_E_TOPOLOGY : small_clip(cin, F, sh, U.f, &which, &stop);
 #endif
             if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 80 : 81], 1u);       // (diagnostic: tasks the regular clipper took / handed on)
 #ifdef SURTR_STAMP
@@ -672,11 +676,33 @@ __global__ __launch_bounds__(SURTR_LANES) __attribute__((amdgpu_waves_per_eu(SUR
 #endif
             if (err == SC_FALLBACK)
             {
-                err = clip_any<false>(cin, F, S, sh, L, [&](auto& T) -> int {
+                // The general clipper goes on where the regular one stopped: from the solid before that plane (the reference's
+                // compacted solid, :464-495), staged through this workgroup's global scratch (the arrays of the wide topology,
+                // which the LDS variant leaves alone), with the remaining planes.  Anything but success there starts over from
+                // the piece's Convex and all planes, as before.
+                SolidIn cx = cin; uint32_t Fx = F;
+                const bool resumed = SC_RESUME && stop != 0xFFFFFFFFu && stop > 0u && stop < F;
+                if (resumed)
+                {
+                    const uint32_t nvs = U.f.nv[which];
+                    cx = sc_stage(U.f.buf[which], nvs, S.pos, S.g_loff, S.g_llen, S.g_ring);
+                    Fx = F - stop;
+                    for (uint32_t k = tid; k < Fx; k += group_size()) sh.pmar[k] = sh.planes[k + stop];      // (pmar: free until the estimate below)
+                    __syncthreads();
+                    for (uint32_t k = tid; k < Fx; k += group_size()) sh.planes[k] = sh.pmar[k];
+                    __syncthreads();
+                    if (tid == 0) atomicAdd(&A.cursors[78], 1u);       // (diagnostic: general clips resumed from a later plane)
+                }
+                err = clip_any<false>(cx, Fx, S, sh, L, [&](auto& T) -> int {
                     if (T.nLive == 0) return 0;
                     return park_topo(T, sh, A, rec.cv_off, rec.cv_n, rec.ch_off, rec.ch_n);
                 }, &W);
                 __syncthreads();
+                if (resumed)
+                {
+                    for (uint32_t k = tid; k < F; k += group_size()) sh.planes[k] = planes[f0 + k];      // (the cost estimate below and the fall-backs want them all)
+                    __syncthreads();
+                }
             }
             if (err == SURTR_OVERFLOW)
             {
@@ -1846,8 +1872,8 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
         {
             // the regular clipper first: it takes the Convex whose slab planes either cut no vertex (the plane through an extreme
             // vertex of the fragment that is an extreme vertex of its Convex too) or cut with no vertex in the plane
-            uint32_t which = 0;
-            err = small_clip(cin, 8, sh, U.f, &which);
+            uint32_t which = 0, stop = 0xFFFFFFFFu;
+            err = small_clip(cin, 8, sh, U.f, &which, &stop);
             if (tid == 0) atomicAdd(&A.cursors[err == 0 ? 82 : 83], 1u);       // (diagnostic: refits the regular clipper took / handed on)
             if (err == 0)
             {
@@ -1856,10 +1882,33 @@ __global__ __launch_bounds__(SURTR_LANES) void k_refit(FragRec* __restrict__ fra
             }
             __syncthreads();
             if (err == SC_FALLBACK)
-            err = clip_any<false>(cin, 8, S, sh, L, [&](auto& T) -> int {
-                if (T.nLive == 0) return 0;
-                return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
-            }, &W);
+            {
+                // (as in k_clip_convex: the general clipper goes on from the plane the regular one stopped at)
+                SolidIn cx = cin; uint32_t Fx = 8u;
+                const bool resumed = SC_RESUME && stop != 0xFFFFFFFFu && stop > 0u && stop < 8u;
+                float4* const keep = (float4*)S.g_comp;      // (a byte array of the wide topology: 128 bytes of it hold the eight planes meanwhile)
+                if (resumed)
+                {
+                    const uint32_t nvs = U.f.nv[which];
+                    cx = sc_stage(U.f.buf[which], nvs, S.pos, S.g_loff, S.g_llen, S.g_ring);
+                    Fx = 8u - stop;
+                    for (uint32_t k = tid; k < 8u; k += group_size()) { keep[k] = sh.planes[k]; sh.pmar[k] = sh.planes[k]; }
+                    __syncthreads();
+                    for (uint32_t k = tid; k < Fx; k += group_size()) sh.planes[k] = sh.pmar[k + stop];
+                    __syncthreads();
+                    if (tid == 0) atomicAdd(&A.cursors[79], 1u);       // (diagnostic)
+                }
+                err = clip_any<false>(cx, Fx, S, sh, L, [&](auto& T) -> int {
+                    if (T.nLive == 0) return 0;
+                    return park_topo(T, sh, A, nvoff, ncn, nhoff, nchn);
+                }, &W);
+                __syncthreads();
+                if (resumed)
+                {
+                    for (uint32_t k = tid; k < 8u; k += group_size()) sh.planes[k] = keep[k];      // (the fall-backs below start over with all eight)
+                    __syncthreads();
+                }
+            }
             __syncthreads();
 #ifdef SURTR_STAMP
             if (err == SURTR_OVERFLOW) dbg_path |= 1;

@@ -64,6 +64,7 @@ template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; ret
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void __threadfence() {}
+static inline void __threadfence_block() {}
 static inline int __builtin_amdgcn_readlane(int v, int) { return v; }
 static inline int __builtin_amdgcn_update_dpp(int old, int, int, int, int, bool) { return old; }      // lane 0 never has a source lane
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
