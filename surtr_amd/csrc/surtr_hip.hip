@@ -1329,6 +1329,7 @@ __device__ __attribute__((always_inline)) static inline void clip_pairs_wave_bod
     Scratch S{};
     if (FALLBACK) S = carve(pool, wg);
     const uint32_t cbase = cbase_arg ? cbase_arg : (FALLBACK ? 16u : 128u);       // class counts of the table this kernel pulls from
+    if (!FALLBACK && hlist != nullptr && tid == 0) atomicAdd(&A.cursors[147], 1u);      // (the catcher beside this kernel: "it has started")
     while (true)
     {
         __syncthreads();
@@ -1516,27 +1517,41 @@ __global__ __launch_bounds__(SURTR_MAIN_THREADS) __attribute__((amdgpu_waves_per
     clip_pairs_wave_body<WcLdsMain, WcLdsMain, false, true>(lds_raw, blockIdx.x, P, planes, plane_off, cell_begin, n_pairs, pool, A, IA, pairs, pair_list, order, nullptr, 11, 0, 4u, walk0, hlist, 16u);
 }
 
-// The catcher: see above.  n_main: workgroups of k_clip_pairs_main (0: none was launched).  Its workgroups use the scratch slots
-// from wg_base on.  A workgroup that has waited a very long time for a slot gives up with SURTR_E_STATE rather than spin for ever.
+// The catcher: see above.  n_main: workgroups of k_clip_pairs_main.  Its workgroups use the scratch slots from wg_base on.
+// Nothing depends on the two kernels really running side by side: a polling workgroup marks the slot it takes (SURTR_H_TAKEN), leaves
+// when the main kernel has not even started after a few thousand polls (a profiler that serialises kernels, a device with no room
+// for both) or has not finished after a very long wait, and a SWEEP launch of this kernel (sweep != 0) behind both takes whatever
+// slots still hold a pair -- as a rule none: one workgroup looks at the counters and returns.
+#define SURTR_H_TAKEN 0xFFFFFFFEu
 __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_clip_pairs_catch(Pieces P, const float4* __restrict__ planes,
                                                          const uint32_t* __restrict__ plane_off, uint32_t cell_begin,
                                                          uint32_t n_pairs,
                                                          ScratchPool pool, uint32_t wg_base, Arena A, ImgArena IA, PairRec* __restrict__ pairs,
                                                          const uint2* __restrict__ pair_list, const uint32_t* __restrict__ order,
-                                                         uint32_t* __restrict__ hlist, uint32_t hcap, uint32_t n_main)
+                                                         uint32_t* __restrict__ hlist, uint32_t hcap, uint32_t n_main, uint32_t sweep, uint32_t n_poll)
 {
     __shared__ Shared sh;
     __shared__ LdsTopo L;
     const uint32_t tid = threadIdx.x, wg = wg_base + blockIdx.x;
     Scratch S = carve(pool, wg);
-    bool own = true;
+    bool own = sweep == 0u;
     while (true)
     {
         __syncthreads();
         if (tid == 0)
         {
             uint32_t p = 0xFFFFFFFFu;
-            if (own)
+            if (sweep != 0u)
+            {
+                // behind both kernels: the slots that were filled and never taken
+                const uint32_t pushed = A.cursors[146] < hcap ? A.cursors[146] : hcap;
+                for (uint32_t t = atomicAdd(&A.cursors[151], 1u); t < pushed; t = atomicAdd(&A.cursors[151], 1u))
+                {
+                    const uint32_t v = atomicExch(&hlist[t], SURTR_H_TAKEN);
+                    if (v < n_pairs) { p = v; break; }
+                }
+            }
+            else if (own)
             {
                 uint32_t t = atomicAdd(&A.cursors[150], 1u);
                 for (int cls = 13; cls >= 12; --cls)
@@ -1546,7 +1561,7 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                     t -= cnt;
                 }
             }
-            if (p == 0xFFFFFFFFu && (own ? blockIdx.x : 0u) < SURTR_CATCH_POLL)
+            if (sweep == 0u && p == 0xFFFFFFFFu && n_poll != 0u && (own ? blockIdx.x : 0u) < n_poll)
             {
                 // (only the first few workgroups stay for the hand-overs -- a handful per event; the others give their LDS back to the
                 //  main kernel as soon as the irregular pairs are done)
@@ -1555,9 +1570,10 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(2, 4))
                 for (uint32_t spin = 0; t < hcap; ++spin)
                 {
                     const uint32_t v = atomicAdd(&hlist[t], 0u);
-                    if (v != 0xFFFFFFFFu) { p = v; break; }
+                    if (v < n_pairs) { atomicExch(&hlist[t], SURTR_H_TAKEN); p = v; break; }
                     if (atomicAdd(&A.cursors[148], 0u) >= n_main && atomicAdd(&A.cursors[146], 0u) <= t) break;      // nobody will fill it
-                    if (spin > (1u << 22)) { atomicMax(&A.cursors[5], (uint32_t)SURTR_E_STATE); break; }
+                    if (spin > (1u << 12) && atomicAdd(&A.cursors[147], 0u) == 0u) break;      // the main kernel is not running beside this one: the sweep's
+                    if (spin > (1u << 22)) break;                                              // ... or for very long: the sweep's as well
                     __builtin_amdgcn_s_sleep(32);
                 }
             }
@@ -3648,6 +3664,8 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     //  64 and more take LDS from it: 2.50 / 2.50 / 2.56 ms per event with 16 / 32 / 64)
     uint32_t n_catch = std::min(std::min(ctx->n_wg_catch, 32u), std::max(n_pairs, 1u));
     if (const char* e = getenv("SURTR_CATCH_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_catch) n_catch = v; }
+    uint32_t n_poll = SURTR_CATCH_POLL;      // catcher workgroups that wait for hand-overs (tests: 0 = none, everything handed on is the sweep's)
+    if (const char* e = getenv("SURTR_CATCH_POLL")) { const int v = atoi(e); if (v >= 0 && v <= 1024) n_poll = (uint32_t)v; }
     uint32_t heavy_need = 0u;      // (off: k_clip_pairs_big takes 2 x its grid of such pairs and no more -- the rest would land on the catcher)
     if (const char* e = getenv("SURTR_HEAVY_NEED")) { if (split_on) heavy_need = (uint32_t)atoi(e); }
     uint32_t n_wg_rec = 0;
@@ -3763,7 +3781,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     PROF_BEGIN_ON(13, st3);
     if (n_pairs && wave_on && split_on)
         hipLaunchKernelGGL(k_clip_pairs_catch, dim3(n_catch), dim3(SURTR_WG), 0, st3, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
-                           ctx->pool, max_wg + ctx->n_wg_big, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, hcap, n_wg_main);
+                           ctx->pool, max_wg + ctx->n_wg_big, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, hcap, n_wg_main, 0u, n_poll);
     PROF_END_ON(13, st3);
     PROF_BEGIN_ON(9, st3);
     if (n_pairs && use_half)
@@ -3778,6 +3796,10 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     if (n_pairs && use_half)
         hipLaunchKernelGGL(k_clip_pairs, dim3(std::min(n_wg, 64u)), dim3(SURTR_WG), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
                            ctx->pool, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_order + (size_t)32 * ctx->cap_order, -1, 0, 13u);
+    // ... and the sweep of the hand-over list (see k_clip_pairs_catch): normally nothing is left and its workgroups return at once
+    if (n_pairs && wave_on && split_on)
+        hipLaunchKernelGGL(k_clip_pairs_catch, dim3(std::min(n_catch, SURTR_CATCH_POLL)), dim3(SURTR_WG), 0, st_main, P, ctx->d_planes, ctx->d_plane_off, cell_begin, n_pairs,
+                           ctx->pool, max_wg + ctx->n_wg_big, ctx->arena, ctx->img, ctx->d_pairs, d_pair_list, ctx->d_order, ctx->d_hlist, hcap, n_wg_main, 1u, 0u);
     PROF_END_ON(10, st_main);
     HIPCHK(hipEventRecord(ctx->ev_big, st2));      // (the main kernel's stream, or the whole-CU kernel's when the main one runs on `st`)
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));

@@ -59,6 +59,23 @@ def test_record_clipper_emulation_torus(emul_lib_path, oracle, monkeypatch, lib)
         assert sum(int(qs[96 + r]) for r in (4, 7, 9, 10, 16)) > 5, "no pair ran out of room"
 
 
+def test_hand_overs_nobody_polled_for_are_swept(emul_lib_path, oracle, monkeypatch):
+    """The catcher beside the main kernel is an optimisation, not a dependency: with no workgroup polling (as when a profiler
+    serialises the kernels and the catcher runs first), every pair the record clipper hands on is taken by the sweep launch."""
+    from surtr_amd import engine
+    monkeypatch.setenv("SURTR_WAVE", "1"); monkeypatch.setenv("SURTR_CATCH_POLL", "0")
+    engine._use_library_for_tests(os.path.join(os.path.dirname(emul_lib_path), "libsurtr_emul_rec.so"))
+    try:
+        sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+        c, got, ref, qs = _event(engine, oracle, sc, 128)
+    finally:
+        engine._use_library_for_tests(None)
+    assert c.status == 0 and c.n_frag == ref["frag_ids"].shape[0]
+    assert_event_equal(got, ref)
+    handed = int(qs[89])
+    assert handed > 10 and int(qs[94]) >= handed, (handed, int(qs[94]))
+
+
 def test_record_clipper_emulation_islands_and_empty_results(emul_engine, oracle, monkeypatch):
     """Two disjoint cubes in one piece (islands), and cells that keep nothing of the Mesh."""
     monkeypatch.setenv("SURTR_WAVE", "1")
