@@ -41,7 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-IN_FLIGHT_DEFAULT = 3      # events in flight per GPU, at every N
+IN_FLIGHT_DEFAULT = 4      # events in flight per GPU, at every N
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
+# queue run one behind the other.  E events in flight are E contexts x 3 streams: with four queues the kernels of different events
+# -- and the side-by-side kernels of ONE event -- wait for each other although nothing orders them.  One queue per stream
+# (measured on MI355X, configs[3], 60 steps: 4 queues 2.31-2.35 ms per step, 12: 2.17, 16: 2.15-2.18, 32: 2.11-2.14, 64: 2.14-2.16;
+# 512-cell blocks with three in flight 0.81 -> 0.69 ms).  A setting of this process's HIP runtime, made before it starts; whoever
+# embeds the engine with several contexts wants the same.  An explicit value in the environment wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 # CPU tier of the tests only: the single-lane emulation of the kernels (tests/emul) + gloo instead of the HIP library + RCCL, so that
 # the launcher and the N-rank code path can be driven without a GPU.  Never set by the driver; the line then says "data": "emulation".
 EMUL_LIB = os.environ.get("SURTR_BENCH_EMUL_LIB")
@@ -416,6 +423,7 @@ def main():
                                        "BASELINE configs[3]" if (not args.torus and args.cells == 4096) else "NOT the BASELINE configuration"),
                        "cells": sc["n_cells"] * (world if args.scaling == "weak" else 1), "fragments": total_frag,
                        "events_in_flight": max(1, args.in_flight), "setup_events": args.settle,
+                       "hip_hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": ("%d ranks x one %d-cell event each, one all-gather" % (world, sc["n_cells"])) if args.scaling == "weak"
                                       else ("one event, cells sharded x%d in contiguous %s blocks, one all-gather" % (world, "cost-balanced" if args.balanced_blocks else "equal-sized") if world > 1 else "one GPU")},
             "ms_per_fracture_event": single_event_ms,
