@@ -439,7 +439,14 @@ def main():
                          # launch shares the CUs with the kernels of the other events and its duration depends on how the
                          # streams happen to interleave
                          "launch_ms_min_max": [float(np.min(clip_ms)), float(np.max(clip_ms))], "launches_timed": len(clip_ms),
-                         "avg_launch_ms_alone": dom_alone_ms},
+                         "avg_launch_ms_alone": dom_alone_ms,
+                         # one launch per step: average duration / time per step = how many launches of this kernel run at once
+                         # (each hardware queue its own stream: the launches of the events in flight overlap, each on part of
+                         # the CUs, and `achieved` -- bytes of ONE launch over ITS duration -- halves when two share the GPU);
+                         # all the launches running at a time together move `achieved_all_launches`
+                         "launches_in_flight": clip_avg_ms / ms_per_step,
+                         "achieved_all_launches": achieved * max(1.0, clip_avg_ms / ms_per_step),
+                         "frac_all_launches": achieved * max(1.0, clip_avg_ms / ms_per_step) / HBM_PEAK_GBS},
             # pre-pass + Mesh clip TOGETHER (one event alone on the GPU): the band of every pair is what the path moves between the
             # two, so their summed counter traffic against the same algorithmic bytes is the honest re-read factor
             "roofline_front_half": {"kernels": [rec.get("prep_kernel", "k_prep_pairs") if traffic_prep is not None else "k_prep_pairs", dom], "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
