@@ -3,11 +3,12 @@
 N-rank throughput relative to the whole event with the same E (a prediction: all-gather and the other ranks' jitter are not in it).
 Usage: python scripts/bench_slices_inflight.py N [E]"""
 import sys, os, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")      # as bench.py: a hardware queue per stream
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from surtr_amd import engine as E_, scenes as S
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-E = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # bench.py's IN_FLIGHT_DEFAULT
 sc = S.torus_scene(4096)
 engs, streams = [], []
 for k in range(E):

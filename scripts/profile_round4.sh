@@ -29,7 +29,7 @@ for w in blob64 blob1024 block8; do
   python scripts/timeline.py run $w 2>&1 | grep "^event" | tail -3 >> $OUT/timeline_$w.txt
 done
 python scripts/cvx_diag.py 2>&1 | grep -v amdgpu.ids > $OUT/one_wave_take_rates.txt; cat $OUT/one_wave_take_rates.txt
-GPU_MAX_HW_QUEUES=32 python scripts/bench_slices_inflight.py 8 4 2>&1 | grep -v amdgpu.ids | tail -2 > $OUT/slices_inflight.txt; cat $OUT/slices_inflight.txt
+python scripts/bench_slices_inflight.py 8 2>&1 | grep -v amdgpu.ids | tail -2 > $OUT/slices_inflight.txt; cat $OUT/slices_inflight.txt
 for n in 2 4 8; do python scripts/bench_slices.py $n > $OUT/slices${n}.log 2>&1; tail -1 $OUT/slices${n}.log; done
 cat $OUT/slices2.log $OUT/slices4.log $OUT/slices8.log | grep -v amdgpu.ids > $OUT/slices.txt
 python scripts/bench_cfg23.py 2>&1 | grep -v amdgpu.ids > $OUT/cfg23.log; cut -c1-90 $OUT/cfg23.log
