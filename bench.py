@@ -205,6 +205,7 @@ def main():
             e = engine.Engine(dev_index)
             if not emul:
                 e.set_stream(st.cuda_stream)
+            e.set_events_in_flight(E)      # (E contexts busy on this GPU: events of few pairs -- a rank's block -- take the lean kernels)
             engs.append(e); streams.append(st)
         eng = engs[0]
         sc = dict(base)

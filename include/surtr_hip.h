@@ -98,6 +98,13 @@ int surtr_set_stream(surtr_ctx* ctx, void* hip_stream);
 /* The stream the context's kernels (surtr_event_pack_dev included) are launched on: a caller that consumes a device blob on
  * another stream orders the two with an event recorded here. */
 int surtr_get_stream(surtr_ctx* ctx, void** hip_stream);
+/* How many contexts the host keeps busy on this GPU at once (default 1).  It changes no result, only which kernels an event of a
+ * few hundred pairs takes: alone on the GPU such an event is shortest with the arrangement that puts the most threads on every pair
+ * (the wide pre-pass, one workgroup of the general clipper per pair); with other events beside it the lean arrangement (the regular
+ * pre-pass, the record clipper + catcher) leaves them the room and the steps come faster (a 512-cell block of configs[3], four
+ * contexts: 0.65 -> 0.55 ms per step; one at a time 1.29 -> 1.37 ms).  The reference has no counterpart (one event at a time,
+ * Src/Surtr.cpp:178-254). */
+int surtr_set_events_in_flight(surtr_ctx* ctx, uint32_t n);
 /* Override the per-workgroup scratch capacities (vertices, neighbour entries); 0 = automatic. */
 int surtr_set_scratch(surtr_ctx* ctx, uint32_t max_verts, uint32_t max_nbrs);
 /* Override the result arena capacities (vertices, neighbour entries, indices); 0 = automatic. */

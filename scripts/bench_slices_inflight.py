@@ -13,7 +13,7 @@ sc = S.torus_scene(4096)
 engs, streams = [], []
 for k in range(E):
     st = torch.cuda.Stream()
-    e = E_.Engine(0); e.set_stream(st.cuda_stream)
+    e = E_.Engine(0); e.set_stream(st.cuda_stream); e.set_events_in_flight(E)
     if k == 0: sc["convex"], _ = S.ach_convex(e, sc["mesh"]["pos"])
     e.upload_pieces([sc["mesh"]], [sc["convex"]]); e.upload_pattern(sc["face_off"], sc["v012"]); e.place_cells(sc["scale"], sc["translate"])
     engs.append(e); streams.append(st)

@@ -239,6 +239,7 @@ struct surtr_ctx
     hipStream_t stream2 = nullptr;   // k_clip_pairs runs here, beside k_clip_pairs_big on the caller's stream
     hipStream_t stream3 = nullptr;   // k_clip_pairs_half (+ the retry launch) beside both
     hipEvent_t ev_prep = nullptr, ev_big = nullptr, ev_half = nullptr, ev_cvx = nullptr;
+    uint32_t events_in_flight = 1;      // surtr_set_events_in_flight: contexts the host keeps busy on this GPU at once
     hipStream_t stream = nullptr;
     std::string err;
     // pieces

@@ -3634,7 +3634,13 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // the general clipper takes 0.26 (configs[1]: 0.73 -> 0.72 ms per event, configs[2]: 1.06 -> 1.00)
     // (SURTR_HALF=1 -- tests that want the half-size general kernel -- keeps such events on it)
     const bool half_forced = getenv("SURTR_HALF") != nullptr && atoi(getenv("SURTR_HALF")) != 0;
-    bool wave_on = 2u * n_pairs > 3u * max_wg || (!half_forced && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= 4u * SURTR_REC_MAXN);
+    // (several contexts busy on the GPU, surtr_set_events_in_flight: the lean arrangement for events of any size whose pieces the
+    //  split arrangement takes -- the record clipper's 0.27 ms per pair against the general clipper's 0.55 leave the other events
+    //  the LDS; blocks of configs[3] with four contexts: 512 cells 0.65 -> 0.55 ms per step, 1 024 cells 0.84 -> 0.75, 2 048 cells
+    //  1.40 -> 1.21; one at a time 1.29 -> 1.37 / 1.45 -> 1.44 / 1.73 -> 1.78)
+    const bool many = ctx->events_in_flight > 1u && !half_forced;
+    bool wave_on = 2u * n_pairs > 3u * max_wg || (!half_forced && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= 4u * SURTR_REC_MAXN) ||
+                   (many && ctx->vmin >= SURTR_PREP_MINV && ctx->vmax <= ctx->prep.VMAX);
     if (const char* e = getenv("SURTR_WAVE")) wave_on = atoi(e) != 0;
     uint32_t rec_on = wave_on ? 1u : 0u;
     if (const char* e = getenv("SURTR_REC")) rec_on = (wave_on && atoi(e) != 0) ? 1u : 0u;      // (tests / A-B: 0 = images + wc_load as in round 3)
@@ -3691,7 +3697,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     // Measured per event, one at a time: configs[1] 0.64 -> 0.58 ms, configs[2] 0.92 -> 0.875; not for the wide pre-pass of a block
     // of large pieces (1 024 threads a pair: beside k_clip_convex it takes twice as long, 512-cell block of configs[3] 1.16 -> 1.19 ms)
     // nor for events whose pairs queue up (configs[3]: 2.47 -> 2.71 ms, the cost order and the 761 skipped pairs are worth more).
-    const bool prep_wide = n_pairs != 0 && n_pairs <= wide_max && ctx->vmax >= 8192u;      // few pairs, large meshes
+    const bool prep_wide = n_pairs != 0 && n_pairs <= wide_max && ctx->vmax >= 8192u && !many;      // few pairs, large meshes, nothing else on the GPU
     bool front_par = n_pairs != 0 && n_pairs <= SURTR_FRONT_PAR_MAX && !prep_wide;
     if (const char* e = getenv("SURTR_FRONT_PAR")) front_par = n_pairs != 0 && atoi(e) != 0;
     hipStream_t st_cvx = st;
@@ -4253,6 +4259,13 @@ int surtr_debug_stamps(unsigned long long out[96], int reset)
     return SURTR_OK;
 }
 #endif
+
+int surtr_set_events_in_flight(surtr_ctx* ctx, uint32_t n)
+{
+    if (!ctx) return SURTR_E_INVALID;
+    ctx->events_in_flight = n ? n : 1u;
+    return SURTR_OK;
+}
 
 int surtr_set_profiling(surtr_ctx* ctx, int on)
 {

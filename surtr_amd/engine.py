@@ -165,6 +165,10 @@ class Engine:
         names = ("clip_pairs", "frag_table", "refit", "faces", "out_scan", "pack", "clip_convex", "prep_pairs", "clip_pairs_big", "clip_pairs_half", "clip_pairs_retry", "clip_pairs_wave", "clip_pairs_rec", "clip_pairs_catch")
         return {n: float(ms[i]) for i, n in enumerate(names)}
 
+    def set_events_in_flight(self, n):
+        """Tells the context how many contexts the host keeps busy on this GPU (include/surtr_hip.h: surtr_set_events_in_flight)."""
+        self._ck(lib().surtr_set_events_in_flight(self._h, ctypes.c_uint32(int(n))))
+
     def kernel_history(self):
         """Durations (ms) of the Mesh clip kernel over the last events, oldest first (surtr_kernel_history)."""
         ms = (ctypes.c_float * 16)(); slot = (ctypes.c_int * 16)(); n = ctypes.c_uint32(0)

@@ -50,6 +50,25 @@ def test_sorted_prepass_emulation_equals_oracle(emul_engine, oracle, monkeypatch
         assert (rec_images == 0) if env.get("SURTR_REC") == "0" else (rec_images > 20)
 
 
+def test_events_in_flight_hint_changes_the_kernels_not_the_event(emul_engine, oracle):
+    """surtr_set_events_in_flight(4): an event of 96 pairs takes the record clipper + catcher instead of the general clipper
+    (it would not by its size); the result is the oracle's either way."""
+    sc = scenes.make_scene(*meshgen.bumpy_torus(100, 60), 256)
+    eng = emul_engine.Engine(0)
+    try:
+        eng.upload_pieces([sc["mesh"]], [sc["convex"]]); eng.upload_pattern(sc["face_off"], sc["v012"]); eng.place_cells(sc["scale"], sc["translate"])
+        c1 = eng.fracture_event(0, 96, flags=3); q1 = eng.queue_stats(); g1 = eng.download()
+        eng.set_events_in_flight(4)
+        c2 = eng.fracture_event(0, 96, flags=3); q2 = eng.queue_stats(); g2 = eng.download()
+    finally:
+        eng.close()
+    planes = oracle.place_cells(sc["v012"], sc["scale"], sc["translate"])
+    ref = oracle.event([sc["mesh"]], [sc["convex"]], sc["face_off"], planes, cell_end=96)
+    assert c1.status == 0 and c2.status == 0
+    assert_event_equal(g1, ref); assert_event_equal(g2, ref)
+    assert int(q2[88]) > 30, "with the hint the record clipper takes the pairs"
+
+
 @pytest.mark.parametrize("lib", ["libsurtr_emul.so", "libsurtr_emul_rec.so"])
 def test_small_tier_hands_pairs_on_and_the_event_stands(emul_lib_path, oracle, monkeypatch, lib):
     """k_clip_pairs_rec (three workgroups per CU, no general clipper inside): with little room its pairs leave their stage in
