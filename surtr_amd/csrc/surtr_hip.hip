@@ -1610,7 +1610,7 @@ __global__ __launch_bounds__(SURTR_WG) void k_clip_pairs_wave_big(Pieces P, cons
 
 // -------------------------------------------------------------- k_frag_table
 // One workgroup: exclusive scan of islands per pair -> fragment records in cell-major order.
-__global__ __launch_bounds__(SURTR_WG) void k_frag_table(const PairRec* __restrict__ pairs, uint32_t n_pairs,
+__global__ __launch_bounds__(SURTR_WG_WIDE) void k_frag_table(const PairRec* __restrict__ pairs, uint32_t n_pairs,
                                                          uint32_t n_pieces, uint32_t cell_begin, Arena A,
                                                          uint2* __restrict__ blk, FragRec* __restrict__ frags,
                                                          uint32_t cap_frags, surtr_counts* __restrict__ counts,
@@ -2940,7 +2940,8 @@ __global__ __launch_bounds__(SURTR_WG) __attribute__((amdgpu_waves_per_eu(4, 8))
 }
 
 // --------------------------------------------------------------- k_out_scan
-__global__ __launch_bounds__(SURTR_WG) void k_out_scan(FragRec* __restrict__ frags, uint2* __restrict__ blk,
+// (1 024 threads: one workgroup's scans over a few thousand records are chains of L2 round trips -- more threads, fewer links)
+__global__ __launch_bounds__(SURTR_WG_WIDE) void k_out_scan(FragRec* __restrict__ frags, uint2* __restrict__ blk,
                                                        surtr_counts* __restrict__ counts, Arena A)
 {
     __shared__ Shared sh;
@@ -3810,7 +3811,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     HIPCHK(hipEventRecord(ctx->ev_big, st2));      // (the main kernel's stream, or the whole-CU kernel's when the main one runs on `st`)
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
     PROF_BEGIN(1);
-    hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
+    hipLaunchKernelGGL(k_frag_table, dim3(1), dim3(SURTR_WG_WIDE), 0, st, ctx->d_pairs, n_pairs, ctx->n_pieces, cell_begin, ctx->arena,
                        ctx->d_scanblk, ctx->d_frags, ctx->cap_frags, ctx->d_counts, d_pair_list, ctx->d_forder);
     PROF_END(1);
     // refit (Convex) and faces (Mesh) of the fragments are independent: side by side on the two streams
@@ -3858,7 +3859,7 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_big, 0));
     }
     PROF_BEGIN(4);
-    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG_WIDE), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     PROF_END(4);
     HIPCHK(hipGetLastError());
     ctx->have_event = true; ctx->last_flags = flags; ctx->last_current = false; ctx->frags_of_pieces = true;
@@ -3964,7 +3965,7 @@ int surtr_event_refit(surtr_ctx* ctx)
     hipLaunchKernelGGL(k_refit, dim3(ctx->n_wg_small), dim3(SURTR_LANES), 0, st, ctx->d_frags, ctx->d_counts, ctx->pool_small, ctx->arena, ctx->d_forder, ctx->cap_frags, ctx->d_frag_status,
                        ctx->frags_of_pieces ? (const float*)ctx->cset.pos : (const float*)nullptr, ctx->frags_of_pieces ? (const uint32_t*)ctx->cset.vo : (const uint32_t*)nullptr);
     PROF_END(2);
-    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG_WIDE), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
     ctx->last_flags |= SURTR_EVT_REFIT; ctx->last_current = false;
     return SURTR_OK;
@@ -3993,7 +3994,7 @@ static int launch_faces(surtr_ctx* ctx, uint32_t fan, uint32_t* d_face_n, uint32
                            ctx->blk_per_wg_big, ctx->arena, ctx->d_forder, ctx->cap_frags, fan, d_face_n, d_face_off, d_face_idx, ctx->d_frag_status,
                            (const uint32_t*)ctx->d_face_list, (uint32_t*)nullptr);
     PROF_END(3);
-    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG_WIDE), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
     ctx->last_flags |= SURTR_EVT_RENDER; ctx->last_current = false;
     return SURTR_OK;
@@ -4070,7 +4071,7 @@ int surtr_load_fragments(surtr_ctx* ctx, uint32_t n, const uint32_t* mvo, const 
     HIPCHK(hipMemcpyAsync(ctx->arena.cursors, cursors.data(), 512, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->d_counts, &c, sizeof(c), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(ctx->d_frag_status, 0, (size_t)ctx->cap_frags * 4, st));
-    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
+    hipLaunchKernelGGL(k_out_scan, dim3(1), dim3(SURTR_WG_WIDE), 0, st, ctx->d_frags, ctx->d_scanblk, ctx->d_counts, ctx->arena);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));       // the staging vectors go out of scope
     ctx->have_event = true; ctx->last_flags = 0; ctx->last_current = false; ctx->frags_of_pieces = false;
