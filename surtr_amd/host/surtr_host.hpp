@@ -238,6 +238,9 @@ public:
     struct FlaggedUnits { uint32_t n_failed = 0; std::vector<std::pair<int, int>> pairs /* (cell, piece): no fragment */; std::vector<uint32_t> fragments /* output index */; };
     void AllowFlagged(bool allow) { allow_flagged_ = allow; }
     const FlaggedUnits& LastFlagged() const { return flagged_; }
+    // How many engines the host keeps busy on this GPU at once (surtr_set_events_in_flight: no result changes, events of a few
+    // hundred pairs then take the kernels that leave the other engines room).  The reference runs one event at a time.
+    void SetEventsInFlight(uint32_t n) { check(surtr_set_events_in_flight(ctx_, n), "surtr_set_events_in_flight"); }
     surtr_ctx* Raw() { return ctx_; }
 
 private:
