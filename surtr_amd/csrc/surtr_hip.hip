@@ -3671,7 +3671,11 @@ static int launch_event(surtr_ctx* ctx, uint32_t cell_begin, uint32_t n_pairs, c
     //  64 and more take LDS from it: 2.50 / 2.50 / 2.56 ms per event with 16 / 32 / 64)
     uint32_t n_catch = std::min(std::min(ctx->n_wg_catch, 32u), std::max(n_pairs, 1u));
     if (const char* e = getenv("SURTR_CATCH_WG")) { const uint32_t v = (uint32_t)atoi(e); if (v > 0 && v <= ctx->n_wg_catch) n_catch = v; }
-    uint32_t n_poll = SURTR_CATCH_POLL;      // catcher workgroups that wait for hand-overs (tests: 0 = none, everything handed on is the sweep's)
+    // catcher workgroups that wait for hand-overs (tests: 0 = none, everything handed on is the sweep's).  With other contexts busy on
+    // the GPU (surtr_set_events_in_flight) two: a polling workgroup holds 78 KB of LDS for the length of the main kernel, which the
+    // other events' kernels want (configs[3], four contexts, 60 steps: 2.15 -> 2.09 ms per step; one poller: 2.08, but then the two
+    // hand-overs of an event wait for each other, one event 2.38 -> 2.54 ms)
+    uint32_t n_poll = ctx->events_in_flight > 1u ? 2u : SURTR_CATCH_POLL;
     if (const char* e = getenv("SURTR_CATCH_POLL")) { const int v = atoi(e); if (v >= 0 && v <= 1024) n_poll = (uint32_t)v; }
     uint32_t heavy_need = 0u;      // (off: k_clip_pairs_big takes 2 x its grid of such pairs and no more -- the rest would land on the catcher)
     if (const char* e = getenv("SURTR_HEAVY_NEED")) { if (split_on) heavy_need = (uint32_t)atoi(e); }
