@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-IN_FLIGHT_DEFAULT = 4      # events in flight per GPU, at every N
+IN_FLIGHT_DEFAULT = 6      # events in flight per GPU, at every N
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
 # queue run one behind the other.  E events in flight are E contexts x 3 streams: with four queues the kernels of different events
 # -- and the side-by-side kernels of ONE event -- wait for each other although nothing orders them.  One queue per stream
@@ -247,6 +247,9 @@ def main():
         for r in range(args.settle):
             engs[r % len(engs)].fracture_event_async(cb, ce, flags=flags)
         dev_sync()
+        if not emul:
+            free_b, total_b = torch.cuda.mem_get_info(dev)
+            setup_ms["hbm_used_gb"] = round((total_b - free_b) / 2.0 ** 30, 1)      # (all the contexts of this rank, pools included)
         cap_t = torch.tensor([engine.blob_bytes(counts)], dtype=torch.int64, device=dev)
         if multi:
             dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)

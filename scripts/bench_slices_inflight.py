@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from surtr_amd import engine as E_, scenes as S
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-E = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # bench.py's IN_FLIGHT_DEFAULT
+E = int(sys.argv[2]) if len(sys.argv) > 2 else 6      # bench.py's IN_FLIGHT_DEFAULT
 sc = S.torus_scene(4096)
 engs, streams = [], []
 for k in range(E):

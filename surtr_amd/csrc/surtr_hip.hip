@@ -3378,6 +3378,9 @@ static int ensure_scratch(surtr_ctx* ctx, uint32_t need_v, uint32_t need_h, uint
     HIPCHK(hipMalloc((void**)&ctx->pool.base, ctx->pool.per_wg * n_wg));
     const uint32_t HF_full = need_h + need_h / 2 + 8192;
     uint32_t tier = SURTR_FACES_TIER_DEFAULT;
+    // (several contexts on the GPU, surtr_set_events_in_flight: every one of them holds this scratch -- 22 GB at configs[3] with the
+    //  full tier, sized for a fragment as large as the piece; a quarter of it, and the second tier takes the fragments beyond)
+    if (ctx->events_in_flight > 1u) tier /= 4u;
     if (const char* e = getenv("SURTR_FACES_TIER_HE")) { const long v = atol(e); if (v >= 64) tier = (uint32_t)v; }
     ctx->fs.HF = std::min(HF_full, tier);
     ctx->fs.per_wg = (size_t)12 * ctx->fs.HF;

@@ -26,7 +26,7 @@ def test_gpus_2_starts_two_ranks_and_prints_one_line(emul_lib_path):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong"
-    assert d["config"]["events_in_flight"] == 4                       # the same setting at every N
+    assert d["config"]["events_in_flight"] == 6                       # the same setting at every N
     assert "equal-sized" in d["config"]["parallelism"]
     assert d["config"]["fragments"] > 0 and d["value"] > 0
     assert d["weak_scaled"]["cells"] == 16
@@ -34,7 +34,7 @@ def test_gpus_2_starts_two_ranks_and_prints_one_line(emul_lib_path):
                {"SURTR_BENCH_EMUL_LIB": emul_lib_path})
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.strip()][0])
-    assert d1["n_gpus"] == 1 and d1["config"]["events_in_flight"] == 4
+    assert d1["n_gpus"] == 1 and d1["config"]["events_in_flight"] == 6
     assert d1["config"]["fragments"] == d["config"]["fragments"]      # the sharded event is the whole event
 
 
