@@ -3186,6 +3186,8 @@ int surtr_create(int device, surtr_ctx** out)
         hipEventCreateWithFlags(&ctx->ev_cvx, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_big, hipEventDisableTiming) != hipSuccess) { surtr_destroy(ctx); return SURTR_E_HIP; }
+    // (tests / fuzzers: the arrangement of several busy contexts without the call)
+    if (const char* e = getenv("SURTR_EVENTS_IN_FLIGHT")) { const int v = atoi(e); if (v > 0) ctx->events_in_flight = (uint32_t)v; }
     *out = ctx;
     return SURTR_OK;
 }
