@@ -42,7 +42,21 @@ def main():
         if use_ach:
             sc["convex"], _ = S.ach_convex(eng, sc["mesh"]["pos"])
         flags = int(rng.choice([0, 1, 2, 3, 3, 3]))
-        eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        try:
+            eng.upload_pieces([sc["mesh"]], [sc["convex"]])
+        except E.SurtrError:
+            # the ACH of a box whose slabs coincide with its faces: the reference's own clip of the 2x box (Kdop::Calc) leaves a solid
+            # that is no polyhedron (a vertex with fewer than three neighbours), and the upload refuses it like the reference's
+            # assertion.  Outside the reference's domain -- once the restated reference has been seen to give the same solid.
+            class _OracleClip:
+                def clip_polyhedron(self, solid, planes): return O.clip(solid, planes)
+            ref_c, _ = S.ach_convex(_OracleClip(), sc["mesh"]["pos"])
+            same = use_ach and np.array_equal(ref_c["off"], sc["convex"]["off"]) and np.array_equal(ref_c["nbr"], sc["convex"]["nbr"])
+            if not same or int(np.diff(sc["convex"]["off"].astype(np.int64)).min()) >= 3:
+                raise
+            undefined += 1
+            print("case %d kind %d V %d: ACH refused at upload (no polyhedron in the reference either): outside the reference's domain" % (case, kind, sc["mesh"]["pos"].shape[0]), flush=True)
+            continue
         eng.upload_pattern(sc["face_off"], sc["v012"])
         # the reference places patterns both over the AABB and around an impact point
         scale = sc["scale"] * np.float32(rng.uniform(0.6, 2.2)); shift = sc["translate"] + (rng.uniform(-0.3, 0.3, 3) * sc["scale"]).astype(np.float32)
