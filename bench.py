@@ -197,17 +197,22 @@ def main():
     base["n_cells"] = args.cells
     boot.close()
 
+    made = {}
+
     def setup(mode):
-        """Engines + inputs of this rank for one scaling mode; returns the step closure and what it gathers into."""
+        """Engines + inputs of this rank for one scaling mode; returns the step closure and what it gathers into.
+        (The second mode of a run takes the contexts and streams of the first: new ones would land on hardware queues that the
+        first set's streams still occupy, and the extra figure would measure that.)"""
         E = max(1, args.in_flight)
-        engs, streams = [], []
-        for k in range(E):
+        engs, streams = made.get("engs", []), made.get("streams", [])
+        for k in range(len(engs), E):
             st = current_stream() if E == 1 else new_stream()
             e = engine.Engine(dev_index)
             if not emul:
                 e.set_stream(st.cuda_stream)
             e.set_events_in_flight(E)      # (E contexts busy on this GPU: events of few pairs -- a rank's block -- take the lean kernels)
             engs.append(e); streams.append(st)
+        made["engs"], made["streams"] = engs, streams
         eng = engs[0]
         sc = dict(base)
         # the Voronoi pattern is built on the device (surtr_build_cells) and stays there as every engine's pattern
@@ -373,8 +378,7 @@ def main():
     if multi:
         # the same run also times the other scaling mode (extra key, never the headline)
         other = "weak" if args.scaling == "strong" else "strong"
-        for e in engs:
-            e.close()
+        fence()
         sc2, engs2, step2, last2, cap2, _ = setup(other)
         k2 = max(3, min(args.steps, 10))
         dt2 = timed(step2, 2, k2)
