@@ -675,14 +675,16 @@ def test_graft_entry_smoke():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [8, 4, 2])
-def test_sharded_torus_event_equals_the_whole(gpu_engine, oracle, torus_run, world):
+@pytest.mark.parametrize("world,in_flight", [(8, 1), (4, 1), (2, 1), (8, 6), (4, 6)])
+def test_sharded_torus_event_equals_the_whole(gpu_engine, oracle, torus_run, world, in_flight):
     """The configs[3] event cut into `world` contiguous cell blocks, as the ranks of a strong-sharded run take them (one
-    after the other on this GPU): blocks of at most 2 048 pairs go through k_prep_pairs_wide.  Merged in rank order they
-    are the whole event, bit for bit."""
+    after the other on this GPU): blocks of at most 2 048 pairs go through k_prep_pairs_wide -- or, when the context has been
+    told that several of them share the GPU (surtr_set_events_in_flight, as bench.py's are), through the regular pre-pass beside
+    k_clip_convex and the record clipper + catcher.  Merged in rank order they are the whole event, bit for bit."""
     sc, c_all, got_all, ref = torus_run
     eng = gpu_engine.Engine(0)
     try:
+        eng.set_events_in_flight(in_flight)
         eng.upload_pieces([sc["mesh"]], [sc["convex"]])
         eng.upload_pattern(sc["face_off"], sc["v012"])
         eng.place_cells(sc["scale"], sc["translate"])

@@ -103,7 +103,9 @@ def test_faces_that_are_no_triangles_take_the_face_walks(emul_engine, oracle, mo
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{}, {"SURTR_REC_MAXN": "100000"}, {"SURTR_REC": "0"}, {"SURTR_PREP_SORTED": "0"}, {"SURTR_SMALL": "1"},
                                  # (the arrangement of small events -- k_clip_convex beside the pre-pass kernel -- on the large one)
-                                 {"SURTR_FRONT_PAR": "1"}])
+                                 {"SURTR_FRONT_PAR": "1"},
+                                 # (what bench.py's contexts run with: six of them on the GPU -- two polling catchers, a quarter of the faces tier)
+                                 {"SURTR_EVENTS_IN_FLIGHT": "6"}])
 def test_torus_4096_digest_whatever_the_prepass(gpu_engine, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
